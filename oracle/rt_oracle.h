@@ -1,0 +1,116 @@
+/* TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, FP64 restatement of the reference ray tracer's hot path (primary-ray generation,
+ * brute-force closest hit over analytic primitives, Blinn-Phong shading with hard shadows,
+ * Fresnel-weighted mirror bounces, gamma).  It is the checker for the HIP path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product library
+ * never links, loads or calls anything in this directory.
+ *
+ * Parity status: PINNED.  Every function here is checked bit-for-bit (hit ids, distances,
+ * hit records, 8-bit colours) against the real reference engine compiled from its own sources
+ * (oracle/_ref, built by oracle/Makefile) by tests/test_oracle_vs_ref.py in the development
+ * container, and against golden fixtures generated from that engine (tests/golden/) everywhere.
+ * The triangle primitive is the one exception: the reference has no triangle, so it is pinned only
+ * indirectly (two triangles of a parallelogram against the reference Plane).
+ *
+ * Arithmetic follows the reference operation by operation so that results agree to the last bit
+ * when compiled without FMA contraction (-ffp-contract=off, no -ffast-math).
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Primitive kinds; the numeric order is the reference's primitive-id order
+ * (cubes, planes, cylinders, spheres: s2899221/Code/raytracer.cpp:20-27); triangles come last. */
+enum { RTO_CUBE = 0, RTO_PLANE = 1, RTO_CYLINDER = 2, RTO_SPHERE = 3, RTO_TRIANGLE = 4 };
+
+/* One primitive as the reference's constructors take it (s2899221/Code/mesh.h:81,107,132,153):
+ *   cube / cylinder : q[0..2] translation, q[3..5] roll,pitch,yaw, q[6..8] scale
+ *   sphere          : q[0..2] location, q[3..5] scale
+ *   plane           : q[0..11] four corners
+ *   triangle        : q[0..8] three corners
+ * followed by the material block of mesh.h:52-59. */
+typedef struct rto_prim {
+    int32_t kind;
+    int32_t reserved;
+    double  q[12];
+    double  alpha, metallic, roughness, ior;
+    double  albedo[3];
+} rto_prim;
+
+typedef struct rto_light { double pos[3]; double intensity; } rto_light;
+
+/* Camera state of s2899221/Code/persp_camera.h:29-36; rot is row-major, columns right/up/forward. */
+typedef struct rto_camera {
+    double  pos[3];
+    double  rot[9];
+    double  focal, sensor_w, sensor_h;
+    int32_t width, height;
+} rto_camera;
+
+typedef struct rto_hit {
+    int32_t hit;         /* 1 when something was hit */
+    int32_t id;          /* primitive index, -1 on miss */
+    double  dist;        /* distance along the ray, +inf on miss */
+    double  p[3], n[3], r[3];
+    double  u, v;
+} rto_hit;
+
+typedef struct rto_scene {
+    const rto_prim*  prims;  int64_t n_prims;
+    const rto_light* lights; int64_t n_lights;
+} rto_scene;
+
+/* 32-byte BVH node shared with the product's flattened layout: internal nodes have count == 0 and
+ * first = index of the left child (the right child is first + 1); leaves hold count > 0 primitive
+ * slots starting at first in the slot->primitive-id table. */
+typedef struct rto_node32 { float lo[3]; uint32_t first; float hi[3]; uint32_t count; } rto_node32;
+
+void rto_camera_look(const double pos[3], const double dir[3], const double* up_or_null, rto_camera* cam);
+void rto_pixel_to_ray(const rto_camera* cam, double px, double py, double o[3], double d[3]);
+
+int  rto_intersect(const rto_prim* prim, const double o[3], const double d[3], rto_hit* out);
+void rto_aabb(const rto_prim* prim, double mn[3], double mx[3]);
+int  rto_closest_hit(const rto_scene* sc, const double o[3], const double d[3], rto_hit* out);
+void rto_shade(const rto_scene* sc, const rto_hit* hit, const double ray_o[3], uint8_t rgb[3]);
+void rto_trace(const rto_scene* sc, const double o[3], const double d[3], int depth, int max_scatters,
+               double min_scatter_intensity, uint8_t rgb[3]);
+
+/* Batched forms (OpenMP over rays / rows; threads <= 0 means "all cores"). */
+void rto_trace_rays(const rto_scene* sc, const double* rays6, int64_t n, rto_hit* out, int threads);
+void rto_shade_rays(const rto_scene* sc, const double* rays6, int64_t n, uint8_t* rgb, int threads);
+/* Primary rays for the pixel rectangle [x0,x0+w) x [y0,y0+h): ids and distances, row-major in the rectangle. */
+void rto_trace_primary(const rto_scene* sc, const rto_camera* cam, int x0, int y0, int w, int h,
+                       int32_t* ids, double* dist, int threads);
+/* Full pixel pipeline (spp = 1): trace, shade, bounces, gamma.  rgb is w*h*3 bytes.  With no lights: all black.
+ * shadow_rays (may be NULL) receives the number of shadow rays cast, n_hits the primary hits. */
+void rto_render(const rto_scene* sc, const rto_camera* cam, int x0, int y0, int w, int h,
+                int max_scatters, double min_scatter_intensity, uint8_t* rgb,
+                int64_t* n_hits, int64_t* shadow_rays, int threads);
+void rto_gamma_lut(uint8_t lut[256]);
+
+/* Closest hit through a flattened BVH with FP32 boxes padded by `pad` and FP64 leaf tests; same
+ * result as rto_closest_hit by construction (tie -> lowest id).  counts[0] += nodes fetched,
+ * counts[1] += primitive records fetched.  t_limit: only hits with dist < t_limit are searched
+ * (pass +inf for a plain closest hit). */
+int  rto_bvh_closest_hit(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim,
+                         const double o[3], const double d[3], float pad, rto_hit* out, int64_t counts[2]);
+/* Shadow verdict with the reference's rule (blocked iff the closest hit lies in (1e-4, L - 1e-4)),
+ * evaluated through the BVH with the early exits the product uses. */
+int  rto_bvh_occluded(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim,
+                      const double o[3], const double d[3], double light_dist, float pad, int64_t counts[2]);
+/* Primary + shadow pass over a rectangle through the BVH (max_scatters = 0 pipeline), counting
+ * node / primitive fetches per ray class: counts[0..1] primary, counts[2..3] shadow. */
+void rto_bvh_render(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim, float pad,
+                    const rto_camera* cam, int x0, int y0, int w, int h, int step,
+                    int32_t* ids, uint8_t* rgb, int64_t counts[4], int64_t* n_hits, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ORACLE_H */
