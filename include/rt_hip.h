@@ -1,0 +1,187 @@
+/* rt_hip.h - C ABI of the MI355X ray-tracing hot path (librt_hip.so).
+ *
+ * The reference engine (kailen-hargenrader/RayTracer, s2899221/Code) has no plugin or FFI layer: its
+ * boundary is a C++ class API.  This C ABI sits directly beneath a host-side mirror of that API
+ * (raytracer_amd/csrc/host/{raytracer,mesh,persp_camera,utils}.h) and is what any binding for the path
+ * calls: each entry point below names the reference interface whose work it takes over.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status; nothing throws across the
+ * boundary; all pointers are caller-owned; "_dev" pointers are device memory on the context's GPU
+ * (hipMalloc, or a torch CUDA tensor's data_ptr); calls on one rt_ctx are ordered on its stream and are
+ * not re-entrant; different contexts (GPUs) may be driven from different host threads.
+ * Primitive ids are indices into the reference's flat primitive list, i.e. cubes, planes, cylinders,
+ * spheres in file order (s2899221/Code/raytracer.cpp:20-27), then triangles (extension); -1 = miss.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* null pointer, bad size, bad rectangle ... */
+    RT_ERR_IO = -2,           /* scene file missing / unreadable */
+    RT_ERR_NOT_FOUND = -3,    /* unknown camera id */
+    RT_ERR_NO_DEVICE = -4,    /* no usable GPU / HIP runtime error at context creation */
+    RT_ERR_HIP = -5,          /* a HIP call failed; rt_last_error() has the text */
+    RT_ERR_NO_SCENE = -6,     /* trace/render called before rt_scene_upload */
+    RT_ERR_LIMIT = -7,        /* size beyond a documented maximum */
+    RT_ERR_PARSE = -8         /* malformed number in a scene file */
+} rt_status;
+
+enum { RT_CUBE = 0, RT_PLANE = 1, RT_CYLINDER = 2, RT_SPHERE = 3, RT_TRIANGLE = 4 };
+
+/* One primitive as the reference constructors take it (s2899221/Code/mesh.h:81,107,132,153):
+ *   cube / cylinder: q[0..2] translation, q[3..5] roll,pitch,yaw (R = Rz Ry Rx), q[6..8] scale
+ *   sphere: q[0..2] location, q[3..5] scale      plane: q[0..11] four corners (corner 2 is ignored by
+ *   the intersector, as in mesh.cpp:799-804)     triangle: q[0..8] three corners
+ * and the material block of mesh.h:52-59.  reserved != 0 on a plane = fewer than four corners were given. */
+typedef struct rt_prim_desc {
+    int32_t kind;
+    int32_t reserved;
+    double  q[12];
+    double  alpha, metallic, roughness, ior;
+    double  albedo[3];
+} rt_prim_desc;
+
+/* PointLight, s2899221/Code/raytracer.h:14-17. */
+typedef struct rt_light { double pos[3]; double intensity; } rt_light;
+
+/* Camera state, s2899221/Code/persp_camera.h:29-36; rot row-major with columns right, up, forward. */
+typedef struct rt_camera {
+    double  pos[3];
+    double  rot[9];
+    double  focal, sensor_w, sensor_h;
+    int32_t width, height;
+} rt_camera;
+
+typedef struct rt_rect { int32_t x0, y0, w, h; } rt_rect;
+
+/* Flattened BVH node, 32 bytes.  count == 0: internal, children at first and first + 1.
+ * count > 0: leaf over primitive slots [first, first + count). */
+typedef struct rt_node32 { float lo[3]; uint32_t first; float hi[3]; uint32_t count; } rt_node32;
+
+typedef struct rt_build_opts {
+    uint32_t max_leaf;        /* primitives per leaf, 1..8 (0 = default 2) */
+    uint32_t sah_bins;        /* 4..32 (0 = default 16) */
+    uint32_t reserved[6];
+} rt_build_opts;
+
+typedef struct rt_scene_info {
+    uint64_t n_prims;         /* primitives in id order */
+    uint64_t n_slots;         /* primitives reachable through the BVH */
+    uint64_t n_loose;         /* primitives tested against every ray (unbounded: a zero / non-finite scale) */
+    uint32_t n_nodes, depth;
+    uint32_t n_lights, n_cameras;
+    uint32_t n_by_kind[8];
+    double   bounds[6];       /* min xyz, max xyz of the bounded primitives */
+    double   radius;          /* max |coordinate| of bounds and lights: scales the FP32 box padding */
+} rt_scene_info;
+
+/* Frame partition for multi-GPU runs: square tiles dealt round-robin (tile t -> rank t % n_ranks);
+ * rank r stores its tiles back to back, each as tile*tile pixels (edge tiles padded). */
+typedef struct rt_tiling { int32_t width, height, tile, n_ranks; } rt_tiling;
+
+typedef struct rt_counters {
+    uint64_t primary_rays, primary_hits, shadow_rays, bounce_rays;
+    uint64_t nodes_primary, prims_primary;   /* V_n, V_p: only filled by the counting variants */
+    uint64_t nodes_shadow, prims_shadow;
+} rt_counters;
+
+typedef struct rt_scene rt_scene;   /* host side: descriptions + flattened records + BVH */
+typedef struct rt_ctx rt_ctx;       /* one GPU: stream, device copy of a scene, scratch outputs */
+
+/* ---- host side: scenes ------------------------------------------------------------------- */
+
+/* Build a scene from in-memory descriptions (ids = array order; the caller is responsible for the
+ * reference's kind order if it wants reference ids).  Takes over what RayTracer keeps after load
+ * (raytracer.h:48-58) plus get_BVH_tree (raytracer.h:78, raytracer.cpp:454-499), re-designed: binned SAH,
+ * FP32 boxes rounded outward, depth <= 31. */
+int rt_scene_create(const rt_prim_desc* prims, uint64_t n_prims, const rt_light* lights, uint32_t n_lights,
+                    const rt_build_opts* opts_or_null, rt_scene** out);
+/* RayTracer::load_from_json (raytracer.h:25, raytracer.cpp:107-121) for the Blender-export format, in
+ * linear time, same defaults; the file's cameras are kept and served by rt_scene_camera. */
+int rt_scene_load_json(const char* path, const rt_build_opts* opts_or_null, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+/* Borrowed views, valid until rt_scene_destroy. */
+int rt_scene_get_prims(const rt_scene* scene, const rt_prim_desc** prims, uint64_t* n);
+int rt_scene_get_lights(const rt_scene* scene, const rt_light** lights, uint32_t* n);
+int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n_nodes,
+                     const uint32_t** slot_prim, uint64_t* n_slots);
+/* Camera by id as read_all_cameras builds it (raytracer.cpp:29-68); RT_ERR_NOT_FOUND if absent.
+ * index >= 0 with id == NULL enumerates cameras in file order; id_out (>= 32 bytes) may be NULL. */
+int rt_scene_camera(const rt_scene* scene, const char* id, int32_t index, rt_camera* out, char* id_out);
+/* World AABB of primitive `id` exactly as the reference's compute_aabb (mesh.cpp:288,517,683,922). */
+int rt_prim_aabb(const rt_prim_desc* prim, double out6[6]);
+
+/* Camera::updateRotationMatrix, both overloads (persp_camera.cpp:35-66); up may be NULL. */
+int rt_camera_look(const double pos[3], const double dir[3], const double* up_or_null, rt_camera* cam);
+/* read_camera_from_json (persp_camera.h:66, persp_camera.cpp:120-168): world-up orientation only. */
+int rt_camera_from_json(const char* path, const char* camera_id, rt_camera* out);
+/* Camera::pixelToRay (persp_camera.cpp:94-118) on the host, for callers that want rays. */
+int rt_camera_pixel_to_ray(const rt_camera* cam, double px, double py, double origin[3], double dir[3]);
+
+/* ---- device side -------------------------------------------------------------------------- */
+
+int rt_ctx_create(int device, rt_ctx** out);
+int rt_ctx_destroy(rt_ctx* ctx);
+/* Launch on the caller's stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * context's own stream. */
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
+int rt_ctx_synchronize(rt_ctx* ctx);
+/* Copy the scene to the context's GPU (synchronous; replaces a previously uploaded scene). */
+int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene);
+
+/* RayTracer::get_one_ray_per_pixel + one_pass_intersection over a pixel rectangle (raytracer.cpp:123-157):
+ * primary rays generated in registers, closest hit.  Outputs row-major in the rectangle; either may be NULL. */
+int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* hit_id_dev, double* dist_dev);
+/* RayTracer::one_pass_intersection (raytracer.h:31) for n arbitrary rays (origin xyz, direction xyz, FP64). */
+int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit_id_dev, double* dist_dev);
+/* one_pass_intersection + RayTracer::shade (raytracer.h:34) for n arbitrary rays: linear 8-bit colour, no gamma. */
+int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb_dev);
+/* RayTracer::render_unaccelerated_ppm's pixel loop with samples_per_pixel = 1 (raytracer.cpp:401-438):
+ * trace, shade with hard shadows, up to max_scatters mirror bounces (<= 8), gamma.  rgb_dev is
+ * rect.w * rect.h * 3 bytes; hit_id_dev (may be NULL) receives the primary hit ids. */
+int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
+                   uint8_t* rgb_dev, int32_t* hit_id_dev);
+/* The same pixel pipeline over this rank's share of a tiled frame; rgb_dev holds
+ * rt_tiles_per_rank(tiling) * tile * tile * 3 bytes. */
+int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int rank, int max_scatters,
+                    double min_scatter_intensity, uint8_t* rgb_dev);
+/* Scatter the gathered per-rank tile buffers (rank-major, as rt_render_tiles wrote them) into a row-major frame. */
+int rt_assemble_tiles(rt_ctx* ctx, rt_tiling tiling, const uint8_t* gathered_dev, uint8_t* frame_rgb_dev);
+int32_t rt_tiles_per_rank(rt_tiling tiling);
+int32_t rt_tile_count(rt_tiling tiling);
+
+/* Ray and (for the counting variants) node / primitive fetch counters accumulated since the last reset. */
+int rt_counters_reset(rt_ctx* ctx);
+int rt_counters_read(rt_ctx* ctx, rt_counters* out);          /* synchronises the stream */
+/* When on, trace / render launches use the instrumented kernels that also count BVH node and primitive
+ * record fetches per ray class (slower; for roofline accounting and tests). */
+int rt_ctx_set_counting(rt_ctx* ctx, int on);
+
+/* Convenience for host-memory callers (the C++ host mirror): whole-frame render / trace into host buffers.
+ * These allocate device scratch inside the context and synchronise. */
+int rt_render_frame_host(rt_ctx* ctx, const rt_camera* cam, int max_scatters, double min_scatter_intensity,
+                         uint8_t* rgb_host, int32_t* hit_id_host_or_null);
+int rt_trace_primary_host(rt_ctx* ctx, const rt_camera* cam, int32_t* hit_id_host, double* dist_host);
+int rt_trace_rays_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, int32_t* hit_id_host, double* dist_host);
+
+/* 256-entry table of the reference's gamma_encode lambda (raytracer.cpp:428-432). */
+int rt_gamma_lut(uint8_t lut[256]);
+
+const char* rt_strerror(int status);
+const char* rt_last_error(void);      /* thread-local detail for the last failing call */
+int rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

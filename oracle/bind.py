@@ -37,6 +37,11 @@ class Camera(C.Structure):
                 ("sensor_w", C.c_double), ("sensor_h", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class Bvh(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_int64), ("slot_prim", C.c_void_p), ("n_slots", C.c_int64),
+                ("n_loose", C.c_int64), ("radius", C.c_float)]
+
+
 class _Scene(C.Structure):
     _fields_ = [("prims", C.c_void_p), ("n_prims", C.c_int64), ("lights", C.c_void_p), ("n_lights", C.c_int64)]
 
@@ -77,11 +82,12 @@ class Oracle:
         L.rto_render.argtypes = [C.POINTER(_Scene), C.POINTER(Camera)] + [C.c_int] * 4 + \
                                 [C.c_int, C.c_double, vp, i64p, i64p, C.c_int]
         L.rto_gamma_lut.argtypes = [vp]
-        L.rto_bvh_closest_hit.argtypes = [C.POINTER(_Scene), vp, vp, dp, dp, C.c_float, vp, i64p]
+        L.rto_bvh_closest_hit.argtypes = [C.POINTER(_Scene), C.POINTER(Bvh), dp, dp, vp, i64p]
         L.rto_bvh_closest_hit.restype = C.c_int
-        L.rto_bvh_occluded.argtypes = [C.POINTER(_Scene), vp, vp, dp, dp, C.c_double, C.c_float, i64p]
+        L.rto_bvh_occluded.argtypes = [C.POINTER(_Scene), C.POINTER(Bvh), dp, dp, C.c_double, i64p]
         L.rto_bvh_occluded.restype = C.c_int
-        L.rto_bvh_render.argtypes = [C.POINTER(_Scene), vp, vp, C.c_float, C.POINTER(Camera)] + [C.c_int] * 5 + \
+        L.rto_bvh_trace_rays.argtypes = [C.POINTER(_Scene), C.POINTER(Bvh), vp, C.c_int64, vp, i64p, C.c_int]
+        L.rto_bvh_render.argtypes = [C.POINTER(_Scene), C.POINTER(Bvh), C.POINTER(Camera)] + [C.c_int] * 5 + \
                                     [vp, vp, i64p, i64p, C.c_int]
 
     # -- helpers -------------------------------------------------------------------------------
@@ -163,32 +169,43 @@ class Oracle:
         self.lib.rto_gamma_lut(_ptr(lut))
         return lut
 
-    def bvh_render(self, scene, nodes, slot_prim, pad, cam, rect=None, step=1, threads=0):
-        """Primary + shadow pass through the flattened BVH; returns ids, rgb, counts[4], hits."""
-        x0, y0, w, h = rect or (0, 0, cam.width, cam.height)
+    @staticmethod
+    def bvh(nodes, slot_prim, n_slots, n_loose, radius):
+        """Descriptor of the product's flattened BVH (numpy views from raytracer_amd.capi.Scene.bvh())."""
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DT)
         slot_prim = np.ascontiguousarray(slot_prim, dtype=np.uint32)
+        b = Bvh(_ptr(nodes), len(nodes), _ptr(slot_prim), int(n_slots), int(n_loose), float(radius))
+        b._keep = (nodes, slot_prim)
+        return b
+
+    def bvh_render(self, scene, bvh, cam, rect=None, step=1, threads=0):
+        """Primary + shadow pass through the flattened BVH; returns ids, rgb, counts[4], hits."""
+        x0, y0, w, h = rect or (0, 0, cam.width, cam.height)
         ow, oh = (w + step - 1) // step, (h + step - 1) // step
         ids = np.empty((oh, ow), dtype=np.int32)
         rgb = np.empty((oh, ow, 3), dtype=np.uint8)
         counts = (C.c_int64 * 4)()
         nh = C.c_int64(0)
-        self.lib.rto_bvh_render(C.byref(scene), _ptr(nodes), _ptr(slot_prim), C.c_float(pad), C.byref(cam),
-                                x0, y0, w, h, step, _ptr(ids), _ptr(rgb), counts, C.byref(nh), threads)
+        self.lib.rto_bvh_render(C.byref(scene), C.byref(bvh), C.byref(cam), x0, y0, w, h, step, _ptr(ids), _ptr(rgb),
+                                counts, C.byref(nh), threads)
         return ids, rgb, np.array(counts[:], dtype=np.int64), nh.value
 
-    def bvh_closest(self, scene, nodes, slot_prim, pad, rays6):
-        nodes = np.ascontiguousarray(nodes, dtype=NODE_DT)
-        slot_prim = np.ascontiguousarray(slot_prim, dtype=np.uint32)
+    def bvh_trace_rays(self, scene, bvh, rays6, threads=0):
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
         out = np.zeros(len(rays6), dtype=HIT_DT)
         counts = (C.c_int64 * 2)()
+        self.lib.rto_bvh_trace_rays(C.byref(scene), C.byref(bvh), _ptr(rays6), len(rays6), _ptr(out), counts, threads)
+        return out, np.array(counts[:], dtype=np.int64)
+
+    def bvh_occluded(self, scene, bvh, rays6, light_dist):
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        light_dist = np.broadcast_to(np.asarray(light_dist, dtype=np.float64), (len(rays6),))
+        out = np.zeros(len(rays6), dtype=np.int32)
         dp = C.POINTER(C.c_double)
         for i in range(len(rays6)):
-            self.lib.rto_bvh_closest_hit(C.byref(scene), _ptr(nodes), _ptr(slot_prim), rays6[i, :3].ctypes.data_as(dp),
-                                         rays6[i, 3:].ctypes.data_as(dp), C.c_float(pad),
-                                         C.c_void_p(out.ctypes.data + i * HIT_DT.itemsize), counts)
-        return out, np.array(counts[:], dtype=np.int64)
+            out[i] = self.lib.rto_bvh_occluded(C.byref(scene), C.byref(bvh), rays6[i, :3].ctypes.data_as(dp),
+                                               rays6[i, 3:].ctypes.data_as(dp), float(light_dist[i]), None)
+        return out
 
 
 REC_DOUBLES = 16   # oracle/ref_harness.cpp HitRecord

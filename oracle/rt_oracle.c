@@ -671,17 +671,22 @@ void rto_render(const rto_scene* sc, const rto_camera* cam, int x0, int y0, int 
 /* flattened-BVH traversal (restates the product's traversal, not the reference's BVH)         */
 
 typedef struct {
-    const rto_scene* sc; const rto_node32* nodes; const uint32_t* slot_prim; float pad; int64_t* counts;
+    const rto_scene* sc; const rto_bvh* bvh; int64_t* counts;
 } bvh_ctx;
 
 typedef struct { float op[3], om[3], inv[3]; } box_ray;   /* origin +/- pad, reciprocal direction */
 
-static void box_ray_init(box_ray* br, const double o[3], const double d[3], float pad) {
+static void box_ray_init(box_ray* br, const double o[3], const double d[3], float radius) {
+    /* padding = 2^-18 * max(|origin|, scene radius); direction normalised before the FP32 reciprocal */
+    const float ox = (float)o[0], oy = (float)o[1], oz = (float)o[2];
+    const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
+    const float pad = ldexpf(m, -18);
+    const double d_len = sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+    const float of[3] = { ox, oy, oz };
     for (int k = 0; k < 3; ++k) {
-        const float of = (float)o[k];
-        br->op[k] = of + pad;
-        br->om[k] = of - pad;
-        br->inv[k] = 1.0f / (float)d[k];
+        br->op[k] = of[k] + pad;
+        br->om[k] = of[k] - pad;
+        br->inv[k] = 1.0f / (float)(d[k] / d_len);
     }
 }
 
@@ -708,75 +713,89 @@ static float f32_up(double x) {            /* smallest float >= max(x, 0); NaN -
 
 #define RTO_STACK 64
 
+typedef struct {
+    const bvh_ctx* c; const double* o; const double* d; int mode; double light_dist;
+    rto_hit best; double limit; float limit_f; int found_mid; int64_t vp;
+} walk_state;
+
+/* One primitive slot; returns 1 when the walk can stop (shadow mode: a hit at <= 1e-4). */
+static int walk_slot(walk_state* w, uint32_t slot) {
+    const uint32_t pid = w->c->bvh->slot_prim[slot];
+    rto_hit h; w->vp += 1;
+    if (!rto_intersect(&w->c->sc->prims[pid], w->o, w->d, &h)) return 0;
+    if (w->mode == 0) {
+        if (h.dist < w->best.dist || (h.dist == w->best.dist && (int32_t)pid < w->best.id)) {
+            w->best = h; w->best.id = (int32_t)pid;
+            w->limit = h.dist; w->limit_f = f32_up(w->limit);
+        }
+    } else {
+        if (h.dist <= 1e-4) return 1;                                   /* the closest hit is not beyond eps */
+        if (h.dist < w->light_dist - 1e-4 && !w->found_mid) {
+            w->found_mid = 1; w->limit = 1e-4; w->limit_f = f32_up(w->limit);   /* now only hits <= eps matter */
+        }
+    }
+    return 0;
+}
+
 /* Generic walk.  mode 0: closest hit (tie -> lowest id).  mode 1: shadow verdict for a light at
  * light_dist - returns 1 when blocked by the reference's rule. */
 static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int mode, double light_dist, rto_hit* out) {
-    box_ray br; box_ray_init(&br, o, d, c->pad);
-    rto_hit best; hit_clear(&best);
-    double limit = (mode == 0) ? RTO_INF : (light_dist - 1e-4);   /* only hits with dist < limit matter */
-    float limit_f = f32_up(limit);
-    int found_mid = 0;
+    const rto_bvh* B = c->bvh;
+    box_ray br; box_ray_init(&br, o, d, B->radius);
+    walk_state w; w.c = c; w.o = o; w.d = d; w.mode = mode; w.light_dist = light_dist;
+    hit_clear(&w.best); w.found_mid = 0; w.vp = 0;
+    w.limit = (mode == 0) ? RTO_INF : (light_dist - 1e-4);   /* only hits with dist < limit matter */
+    w.limit_f = f32_up(w.limit);
     uint32_t stack[RTO_STACK]; int sp = 0;
-    int64_t vn = 0, vp = 0;
+    int64_t vn = 0;
+    int closed = 0;
 
-    rto_node32 cur = c->nodes[0]; vn += 1;
-    int have = (box_entry(&cur, &br, limit_f) != __builtin_inff());
-    for (;;) {
-        if (have) {
-            if (cur.count > 0) {
-                for (uint32_t s = 0; s < cur.count; ++s) {
-                    const uint32_t pid = c->slot_prim[cur.first + s];
-                    rto_hit h; vp += 1;
-                    if (!rto_intersect(&c->sc->prims[pid], o, d, &h)) continue;
-                    if (mode == 0) {
-                        if (h.dist < best.dist || (h.dist == best.dist && (int32_t)pid < best.id)) {
-                            best = h; best.id = (int32_t)pid;
-                            limit = h.dist; limit_f = f32_up(limit);
-                        }
-                    } else {
-                        if (h.dist <= 1e-4) { c->counts[0] += vn; c->counts[1] += vp; return 0; }  /* closest is not beyond eps */
-                        if (h.dist < light_dist - 1e-4 && !found_mid) {
-                            found_mid = 1; limit = 1e-4; limit_f = f32_up(limit);              /* now only look for hits <= eps */
-                        }
-                    }
+    if (B->n_nodes > 0) {
+        rto_node32 cur = B->nodes[0]; vn += 1;
+        int have = (box_entry(&cur, &br, w.limit_f) != __builtin_inff());
+        for (;;) {
+            if (have) {
+                if (cur.count > 0) {
+                    for (uint32_t s = 0; s < cur.count && !closed; ++s) closed = walk_slot(&w, cur.first + s);
+                    if (closed) break;
+                    have = 0;
+                } else {
+                    const rto_node32 l = B->nodes[cur.first], r = B->nodes[cur.first + 1]; vn += 2;
+                    const float tl = box_entry(&l, &br, w.limit_f), tr = box_entry(&r, &br, w.limit_f);
+                    const int hl = tl != __builtin_inff(), hr = tr != __builtin_inff();
+                    if (hl && hr) {
+                        if (tr < tl) { stack[sp++] = cur.first;     cur = r; }
+                        else         { stack[sp++] = cur.first + 1; cur = l; }
+                    } else if (hl) cur = l;
+                    else if (hr) cur = r;
+                    else have = 0;
                 }
-                have = 0;
-            } else {
-                const rto_node32 l = c->nodes[cur.first], r = c->nodes[cur.first + 1]; vn += 2;
-                const float tl = box_entry(&l, &br, limit_f), tr = box_entry(&r, &br, limit_f);
-                const int hl = tl != __builtin_inff(), hr = tr != __builtin_inff();
-                if (hl && hr) {
-                    if (tr < tl) { stack[sp++] = cur.first;     cur = r; }
-                    else         { stack[sp++] = cur.first + 1; cur = l; }
-                } else if (hl) cur = l;
-                else if (hr) cur = r;
-                else have = 0;
+            }
+            if (!have) {
+                if (sp == 0) break;
+                cur = B->nodes[stack[--sp]]; vn += 1;
+                have = (box_entry(&cur, &br, w.limit_f) != __builtin_inff());
             }
         }
-        if (!have) {
-            if (sp == 0) break;
-            cur = c->nodes[stack[--sp]]; vn += 1;
-            have = (box_entry(&cur, &br, limit_f) != __builtin_inff());
-        }
     }
-    c->counts[0] += vn; c->counts[1] += vp;
-    if (mode == 0) { if (out) *out = best; return best.hit; }
-    return found_mid;
+    /* unbounded primitives are tested against every ray */
+    for (uint32_t s = 0; s < B->n_loose && !closed; ++s) closed = walk_slot(&w, (uint32_t)B->n_slots + s);
+    c->counts[0] += vn; c->counts[1] += w.vp;
+    if (mode == 0) { if (out) *out = w.best; return w.best.hit; }
+    return w.found_mid && !closed;
 }
 
-int rto_bvh_closest_hit(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim,
-                        const double o[3], const double d[3], float pad, rto_hit* out, int64_t counts[2]) {
+int rto_bvh_closest_hit(const rto_scene* sc, const rto_bvh* bvh, const double o[3], const double d[3],
+                        rto_hit* out, int64_t counts[2]) {
     int64_t local[2] = { 0, 0 };
-    bvh_ctx c = { sc, nodes, slot_prim, pad, counts ? counts : local };
-    if (sc->n_prims <= 0) { hit_clear(out); return 0; }
+    bvh_ctx c = { sc, bvh, counts ? counts : local };
     return bvh_walk(&c, o, d, 0, 0.0, out);
 }
 
-int rto_bvh_occluded(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim,
-                     const double o[3], const double d[3], double light_dist, float pad, int64_t counts[2]) {
+int rto_bvh_occluded(const rto_scene* sc, const rto_bvh* bvh, const double o[3], const double d[3],
+                     double light_dist, int64_t counts[2]) {
     int64_t local[2] = { 0, 0 };
-    bvh_ctx c = { sc, nodes, slot_prim, pad, counts ? counts : local };
-    if (sc->n_prims <= 0) return 0;
+    bvh_ctx c = { sc, bvh, counts ? counts : local };
     return bvh_walk(&c, o, d, 1, light_dist, 0);
 }
 
@@ -784,9 +803,22 @@ static int bvh_occluded_cb(const void* ctx, const double o[3], const double d[3]
     return bvh_walk((const bvh_ctx*)ctx, o, d, 1, light_dist, 0);
 }
 
-void rto_bvh_render(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim, float pad,
-                    const rto_camera* cam, int x0, int y0, int w, int h, int step,
-                    int32_t* ids, uint8_t* rgb, int64_t counts[4], int64_t* n_hits, int threads) {
+void rto_bvh_trace_rays(const rto_scene* sc, const rto_bvh* bvh, const double* rays6, int64_t n, rto_hit* out,
+                        int64_t counts[2], int threads) {
+    int64_t c0 = 0, c1 = 0;
+    const int nt = pick_threads(threads); (void)nt;
+    #pragma omp parallel for schedule(dynamic, 64) num_threads(nt) reduction(+:c0, c1)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t pc[2] = { 0, 0 };
+        bvh_ctx c = { sc, bvh, pc };
+        bvh_walk(&c, rays6 + i*6, rays6 + i*6 + 3, 0, 0.0, &out[i]);
+        c0 += pc[0]; c1 += pc[1];
+    }
+    if (counts) { counts[0] += c0; counts[1] += c1; }
+}
+
+void rto_bvh_render(const rto_scene* sc, const rto_bvh* bvh, const rto_camera* cam, int x0, int y0, int w, int h,
+                    int step, int32_t* ids, uint8_t* rgb, int64_t counts[4], int64_t* n_hits, int threads) {
     uint8_t lut[256]; rto_gamma_lut(lut);
     if (step < 1) step = 1;
     int64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, hits = 0;
@@ -797,10 +829,10 @@ void rto_bvh_render(const rto_scene* sc, const rto_node32* nodes, const uint32_t
             double o[3], d[3];
             rto_pixel_to_ray(cam, (double)(x0 + xx) + 0.5, (double)(y0 + yy) + 0.5, o, d);
             int64_t pc[2] = { 0, 0 }, sc_[2] = { 0, 0 };
-            bvh_ctx pctx = { sc, nodes, slot_prim, pad, pc };
-            bvh_ctx sctx = { sc, nodes, slot_prim, pad, sc_ };
-            rto_hit hit; hit_clear(&hit);
-            if (sc->n_prims > 0) bvh_walk(&pctx, o, d, 0, 0.0, &hit);
+            bvh_ctx pctx = { sc, bvh, pc };
+            bvh_ctx sctx = { sc, bvh, sc_ };
+            rto_hit hit;
+            bvh_walk(&pctx, o, d, 0, 0.0, &hit);
             uint8_t c[3] = { 0, 0, 0 };
             if (sc->n_lights > 0) shade_with(sc, &hit, o, c, bvh_occluded_cb, &sctx, 0);
             const int64_t k = (int64_t)(yy / step) * ((w + step - 1) / step) + (xx / step);

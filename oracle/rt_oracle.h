@@ -94,21 +94,29 @@ void rto_render(const rto_scene* sc, const rto_camera* cam, int x0, int y0, int 
                 int64_t* n_hits, int64_t* shadow_rays, int threads);
 void rto_gamma_lut(uint8_t lut[256]);
 
-/* Closest hit through a flattened BVH with FP32 boxes padded by `pad` and FP64 leaf tests; same
- * result as rto_closest_hit by construction (tie -> lowest id).  counts[0] += nodes fetched,
- * counts[1] += primitive records fetched.  t_limit: only hits with dist < t_limit are searched
- * (pass +inf for a plain closest hit). */
-int  rto_bvh_closest_hit(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim,
-                         const double o[3], const double d[3], float pad, rto_hit* out, int64_t counts[2]);
+/* The product's flattened BVH, as rt_scene_get_bvh / rt_scene_get_info hand it out: slot_prim maps
+ * primitive slots to ids, the first n_slots in BVH leaf order followed by n_loose unbounded primitives
+ * that every ray tests; radius scales the FP32 box padding (2^-18 * max(|origin|, radius)). */
+typedef struct rto_bvh {
+    const rto_node32* nodes; int64_t n_nodes;
+    const uint32_t* slot_prim; int64_t n_slots; int64_t n_loose;
+    float radius;
+} rto_bvh;
+
+/* Closest hit through the BVH with FP32 padded boxes and FP64 leaf tests; same result as rto_closest_hit by
+ * construction (equal distances -> lowest id).  counts[0] += nodes fetched, counts[1] += primitive records fetched. */
+int  rto_bvh_closest_hit(const rto_scene* sc, const rto_bvh* bvh, const double o[3], const double d[3],
+                         rto_hit* out, int64_t counts[2]);
 /* Shadow verdict with the reference's rule (blocked iff the closest hit lies in (1e-4, L - 1e-4)),
  * evaluated through the BVH with the early exits the product uses. */
-int  rto_bvh_occluded(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim,
-                      const double o[3], const double d[3], double light_dist, float pad, int64_t counts[2]);
-/* Primary + shadow pass over a rectangle through the BVH (max_scatters = 0 pipeline), counting
- * node / primitive fetches per ray class: counts[0..1] primary, counts[2..3] shadow. */
-void rto_bvh_render(const rto_scene* sc, const rto_node32* nodes, const uint32_t* slot_prim, float pad,
-                    const rto_camera* cam, int x0, int y0, int w, int h, int step,
-                    int32_t* ids, uint8_t* rgb, int64_t counts[4], int64_t* n_hits, int threads);
+int  rto_bvh_occluded(const rto_scene* sc, const rto_bvh* bvh, const double o[3], const double d[3],
+                      double light_dist, int64_t counts[2]);
+void rto_bvh_trace_rays(const rto_scene* sc, const rto_bvh* bvh, const double* rays6, int64_t n, rto_hit* out,
+                        int64_t counts[2], int threads);
+/* Primary + shadow pass over a rectangle through the BVH (max_scatters = 0 pipeline), every step-th pixel,
+ * counting node / primitive fetches per ray class: counts[0..1] primary, counts[2..3] shadow. */
+void rto_bvh_render(const rto_scene* sc, const rto_bvh* bvh, const rto_camera* cam, int x0, int y0, int w, int h,
+                    int step, int32_t* ids, uint8_t* rgb, int64_t counts[4], int64_t* n_hits, int threads);
 
 #ifdef __cplusplus
 }

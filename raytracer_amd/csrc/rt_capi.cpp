@@ -1,0 +1,473 @@
+// C ABI of librt_hip.so (include/rt_hip.h): host-side scene handling and kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rt_device.h"
+#include "rt_scene.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+#define RT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+template <class T> int upload(const std::vector<T>& v, T** dev) {
+    *dev = nullptr;
+    if (v.empty()) return RT_OK;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(dev), v.size() * sizeof(T)));
+    RT_HIP(hipMemcpy(*dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool counting = false;
+    bool have_scene = false;
+    DevScene sc{};
+    rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
+    rt_light* d_lights = nullptr; uint8_t* d_gamma = nullptr; rt_counters* d_ctr = nullptr;
+    // grow-only scratch of the *_host conveniences
+    void* scratch[3] = { nullptr, nullptr, nullptr };
+    size_t scratch_bytes[3] = { 0, 0, 0 };
+
+    void free_scene() {
+        if (d_nodes) (void)hipFree(d_nodes);
+        if (d_recs) (void)hipFree(d_recs);
+        if (d_mats) (void)hipFree(d_mats);
+        if (d_lights) (void)hipFree(d_lights);
+        d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr;
+        have_scene = false;
+    }
+    int need(int slot, size_t bytes, void** out) {
+        if (scratch_bytes[slot] < bytes) {
+            if (scratch[slot]) (void)hipFree(scratch[slot]);
+            scratch[slot] = nullptr; scratch_bytes[slot] = 0;
+            RT_HIP(hipMalloc(&scratch[slot], bytes));
+            scratch_bytes[slot] = bytes;
+        }
+        *out = scratch[slot];
+        return RT_OK;
+    }
+};
+
+namespace {
+
+bool camera_ok(const rt_camera* cam) { return cam && cam->width > 0 && cam->height > 0; }
+
+// Effective sensor size: the image-aspect / sensor-aspect branch of Camera::pixelToRay
+// (s2899221/Code/persp_camera.cpp:98-108), evaluated once per launch.
+void to_dev_camera(const rt_camera& c, DevCamera& d) {
+    for (int k = 0; k < 3; ++k) d.pos[k] = c.pos[k];
+    for (int k = 0; k < 9; ++k) d.rot[k] = c.rot[k];
+    const double aspect_img = static_cast<double>(c.width) / static_cast<double>(c.height);
+    const double aspect_sensor = (c.sensor_h > 0.0) ? (c.sensor_w / c.sensor_h) : aspect_img;
+    if (aspect_img >= aspect_sensor) { d.eff_w = c.sensor_w; d.eff_h = d.eff_w / aspect_img; }
+    else                             { d.eff_h = c.sensor_h; d.eff_w = d.eff_h * aspect_img; }
+    d.focal = c.focal;
+    d.width = static_cast<double>(c.width); d.height = static_cast<double>(c.height);
+}
+
+int rect_map(const rt_camera* cam, rt_rect r, PixelMap& pm, uint32_t& n_blocks) {
+    if (r.w <= 0 || r.h <= 0 || r.x0 < 0 || r.y0 < 0 || r.x0 + static_cast<int64_t>(r.w) > cam->width ||
+        r.y0 + static_cast<int64_t>(r.h) > cam->height)
+        return fail(RT_ERR_INVALID, "rectangle outside the camera's film resolution");
+    std::memset(&pm, 0, sizeof(pm));
+    pm.mode = 0; pm.x0 = r.x0; pm.y0 = r.y0; pm.w = r.w; pm.h = r.h;
+    const uint32_t bx = (static_cast<uint32_t>(r.w) + 15u) / 16u, by = (static_cast<uint32_t>(r.h) + 15u) / 16u;
+    pm.super_x = (bx + 7u) / 8u;
+    const uint64_t nb = static_cast<uint64_t>(pm.super_x) * ((by + 7u) / 8u) * 64u;
+    if (nb > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "rectangle too large for one launch");
+    n_blocks = static_cast<uint32_t>(nb);
+    return RT_OK;
+}
+
+int tiling_ok(rt_tiling t) {
+    if (t.width <= 0 || t.height <= 0 || t.n_ranks <= 0 || t.tile < 16 || (t.tile % 16) != 0 || t.tile > 1024)
+        return fail(RT_ERR_INVALID, "tiling: tile must be a multiple of 16 in [16, 1024], sizes and ranks positive");
+    return RT_OK;
+}
+
+int use(rt_ctx* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    RT_HIP(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+int need_scene(rt_ctx* ctx) {
+    if (int rc = use(ctx)) return rc;
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "no scene uploaded to this context");
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// ---- scenes --------------------------------------------------------------------------------------
+
+int rt_scene_create(const rt_prim_desc* prims, uint64_t n_prims, const rt_light* lights, uint32_t n_lights,
+                    const rt_build_opts* opts, rt_scene** out) {
+    if (!out || (n_prims && !prims) || (n_lights && !lights)) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_LIMIT, "out of memory");
+    try {
+        s->prims.assign(prims, prims + n_prims);
+        s->lights.assign(lights, lights + n_lights);
+        const int rc = rt_scene_finalize(s, opts);
+        if (rc != RT_OK) { delete s; return fail(rc, "scene too large"); }
+    } catch (const std::exception& e) { delete s; return fail(RT_ERR_LIMIT, e.what()); }
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_load_json(const char* path, const rt_build_opts* opts, rt_scene** out) {
+    if (!path || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_LIMIT, "out of memory");
+    try {
+        std::string err;
+        int rc = rt_parse_scene_file(path, s->prims, s->lights, s->cameras, err);
+        if (rc == RT_OK) rc = rt_scene_finalize(s, opts);
+        if (rc != RT_OK) { delete s; return fail(rc, err.empty() ? "scene load failed" : err); }
+    } catch (const std::exception& e) { delete s; return fail(RT_ERR_LIMIT, e.what()); }
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* scene) { delete scene; return RT_OK; }
+
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = scene->info; return RT_OK;
+}
+
+int rt_scene_get_prims(const rt_scene* scene, const rt_prim_desc** prims, uint64_t* n) {
+    if (!scene || !prims || !n) return fail(RT_ERR_INVALID, "null argument");
+    *prims = scene->prims.data(); *n = scene->prims.size(); return RT_OK;
+}
+
+int rt_scene_get_lights(const rt_scene* scene, const rt_light** lights, uint32_t* n) {
+    if (!scene || !lights || !n) return fail(RT_ERR_INVALID, "null argument");
+    *lights = scene->lights.data(); *n = static_cast<uint32_t>(scene->lights.size()); return RT_OK;
+}
+
+int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n_nodes, const uint32_t** slot_prim, uint64_t* n_slots) {
+    if (!scene || !nodes || !n_nodes || !slot_prim || !n_slots) return fail(RT_ERR_INVALID, "null argument");
+    *nodes = scene->nodes.data(); *n_nodes = static_cast<uint32_t>(scene->nodes.size());
+    *slot_prim = scene->slot_prim.data(); *n_slots = scene->n_slots;
+    return RT_OK;
+}
+
+int rt_scene_camera(const rt_scene* scene, const char* id, int32_t index, rt_camera* out, char* id_out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID, "null argument");
+    const std::pair<std::string, rt_camera>* found = nullptr;
+    if (id) { for (const auto& kv : scene->cameras) if (kv.first == id) { found = &kv; break; } }
+    else if (index >= 0 && static_cast<size_t>(index) < scene->cameras.size()) found = &scene->cameras[index];
+    if (!found) return fail(RT_ERR_NOT_FOUND, "camera not found");
+    *out = found->second;
+    if (id_out) { std::strncpy(id_out, found->first.c_str(), 31); id_out[31] = 0; }
+    return RT_OK;
+}
+
+int rt_prim_aabb(const rt_prim_desc* prim, double out6[6]) {
+    if (!prim || !out6) return fail(RT_ERR_INVALID, "null argument");
+    rt_reference_aabb(*prim, out6); return RT_OK;
+}
+
+int rt_camera_look(const double pos[3], const double dir[3], const double* up, rt_camera* cam) {
+    if (!pos || !dir || !cam) return fail(RT_ERR_INVALID, "null argument");
+    rt_camera_basis(pos, dir, up, cam); return RT_OK;
+}
+
+int rt_camera_from_json(const char* path, const char* camera_id, rt_camera* out) {
+    if (!path || !camera_id || !out) return fail(RT_ERR_INVALID, "null argument");
+    std::string err;
+    const int rc = rt_parse_camera_file(path, camera_id, out, err);
+    return rc == RT_OK ? RT_OK : fail(rc, err);
+}
+
+int rt_camera_pixel_to_ray(const rt_camera* cam, double px, double py, double origin[3], double dir[3]) {
+    if (!cam || !origin || !dir) return fail(RT_ERR_INVALID, "null argument");
+    rt_pixel_to_ray(cam, px, py, origin, dir); return RT_OK;
+}
+
+int rt_gamma_lut(uint8_t lut[256]) { if (!lut) return fail(RT_ERR_INVALID, "null argument"); rt_gamma_table(lut); return RT_OK; }
+
+// ---- contexts ------------------------------------------------------------------------------------
+
+int rt_ctx_create(int device, rt_ctx** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(RT_ERR_NO_DEVICE, "device index out of range");
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(RT_ERR_LIMIT, "out of memory");
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_ctr), sizeof(rt_counters));
+    if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(rt_counters));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 256);
+    if (e == hipSuccess) { uint8_t lut[256]; rt_gamma_table(lut); e = hipMemcpy(c->d_gamma, lut, 256, hipMemcpyHostToDevice); }
+    if (e != hipSuccess) {
+        const std::string msg = std::string("context creation: ") + hipGetErrorString(e);
+        rt_ctx_destroy(c);
+        return fail(RT_ERR_NO_DEVICE, msg);
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    ctx->free_scene();
+    if (ctx->d_ctr) (void)hipFree(ctx->d_ctr);
+    if (ctx->d_gamma) (void)hipFree(ctx->d_gamma);
+    for (void* p : ctx->scratch) if (p) (void)hipFree(p);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RT_OK;
+}
+
+int rt_ctx_synchronize(rt_ctx* ctx) {
+    if (int rc = use(ctx)) return rc;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_ctx_set_counting(rt_ctx* ctx, int on) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->counting = on != 0; return RT_OK;
+}
+
+int rt_counters_reset(rt_ctx* ctx) {
+    if (int rc = use(ctx)) return rc;
+    RT_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(rt_counters), ctx->stream));
+    return RT_OK;
+}
+
+int rt_counters_read(rt_ctx* ctx, rt_counters* out) {
+    if (!out) return fail(RT_ERR_INVALID, "null argument");
+    if (int rc = use(ctx)) return rc;
+    RT_HIP(hipMemcpyAsync(out, ctx->d_ctr, sizeof(rt_counters), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
+    if (!scene) return fail(RT_ERR_INVALID, "null scene");
+    if (int rc = use(ctx)) return rc;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->free_scene();
+    int rc = upload(scene->nodes, &ctx->d_nodes);
+    if (rc == RT_OK) rc = upload(scene->recs, &ctx->d_recs);
+    if (rc == RT_OK) rc = upload(scene->mats, &ctx->d_mats);
+    if (rc == RT_OK) rc = upload(scene->lights, &ctx->d_lights);
+    if (rc != RT_OK) { ctx->free_scene(); return rc; }
+    DevScene& d = ctx->sc;
+    d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
+    d.n_nodes = static_cast<uint32_t>(scene->nodes.size());
+    d.n_slots = static_cast<uint32_t>(scene->n_slots);
+    d.n_loose = static_cast<uint32_t>(scene->n_loose);
+    d.n_lights = static_cast<uint32_t>(scene->lights.size());
+    // round the radius up: the padding must not shrink through the conversion
+    d.radius = std::nextafterf(static_cast<float>(scene->info.radius), INFINITY);
+    if (!std::isfinite(d.radius)) d.radius = 3.0e38f;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------------
+
+int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* hit_id_dev, double* dist_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam)) return fail(RT_ERR_INVALID, "bad camera (resolution must be positive)");
+    PixelMap pm; uint32_t nb = 0;
+    if (int rc = rect_map(cam, rect, pm, nb)) return rc;
+    DevCamera dc; to_dev_camera(*cam, dc);
+    RT_HIP(rt_launch_trace_primary(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, hit_id_dev, dist_dev, ctx->d_ctr));
+    return RT_OK;
+}
+
+int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit_id_dev, double* dist_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n && !rays6_dev) return fail(RT_ERR_INVALID, "null rays");
+    if (n > 0x7FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, hit_id_dev, dist_dev, nullptr, ctx->d_ctr));
+    return RT_OK;
+}
+
+int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n && (!rays6_dev || !rgb_dev)) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 0x7FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 1, nullptr, nullptr, rgb_dev, ctx->d_ctr));
+    return RT_OK;
+}
+
+int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
+                   uint8_t* rgb_dev, int32_t* hit_id_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !rgb_dev) return fail(RT_ERR_INVALID, "bad camera or null output");
+    if (max_scatters < 0) max_scatters = 0;
+    if (max_scatters > RT_MAX_SCATTERS) return fail(RT_ERR_LIMIT, "max_scatters above 8");
+    PixelMap pm; uint32_t nb = 0;
+    if (int rc = rect_map(cam, rect, pm, nb)) return rc;
+    if (ctx->sc.n_lights == 0) {
+        // no lights: the reference writes an all-black frame without tracing (raytracer.cpp:387-395)
+        RT_HIP(hipMemsetAsync(rgb_dev, 0, static_cast<size_t>(rect.w) * rect.h * 3, ctx->stream));
+        if (hit_id_dev) {
+            DevCamera dc; to_dev_camera(*cam, dc);
+            RT_HIP(rt_launch_trace_primary(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, hit_id_dev, nullptr, ctx->d_ctr));
+        }
+        return RT_OK;
+    }
+    DevCamera dc; to_dev_camera(*cam, dc);
+    RT_HIP(rt_launch_render(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, max_scatters, min_scatter_intensity,
+                            rgb_dev, hit_id_dev, ctx->d_ctr));
+    return RT_OK;
+}
+
+int32_t rt_tile_count(rt_tiling t) {
+    if (t.tile <= 0 || t.width <= 0 || t.height <= 0) return 0;
+    return ((t.width + t.tile - 1) / t.tile) * ((t.height + t.tile - 1) / t.tile);
+}
+
+int32_t rt_tiles_per_rank(rt_tiling t) {
+    if (t.n_ranks <= 0) return 0;
+    return (rt_tile_count(t) + t.n_ranks - 1) / t.n_ranks;
+}
+
+int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int rank, int max_scatters,
+                    double min_scatter_intensity, uint8_t* rgb_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !rgb_dev) return fail(RT_ERR_INVALID, "bad camera or null output");
+    if (int rc = tiling_ok(tiling)) return rc;
+    if (tiling.width != cam->width || tiling.height != cam->height) return fail(RT_ERR_INVALID, "tiling size differs from the camera's film resolution");
+    if (rank < 0 || rank >= tiling.n_ranks) return fail(RT_ERR_INVALID, "rank outside the tiling");
+    if (max_scatters < 0) max_scatters = 0;
+    if (max_scatters > RT_MAX_SCATTERS) return fail(RT_ERR_LIMIT, "max_scatters above 8");
+    const int32_t per_rank = rt_tiles_per_rank(tiling);
+    const size_t bytes = static_cast<size_t>(per_rank) * tiling.tile * tiling.tile * 3;
+    // padding of edge tiles and of a short last round stays zero
+    RT_HIP(hipMemsetAsync(rgb_dev, 0, bytes, ctx->stream));
+    if (ctx->sc.n_lights == 0) return RT_OK;
+    PixelMap pm; std::memset(&pm, 0, sizeof(pm));
+    pm.mode = 1; pm.w = tiling.width; pm.h = tiling.height; pm.tile = tiling.tile;
+    pm.tiles_x = (tiling.width + tiling.tile - 1) / tiling.tile;
+    pm.n_tiles = rt_tile_count(tiling); pm.rank = rank; pm.n_ranks = tiling.n_ranks;
+    const uint32_t bpt = static_cast<uint32_t>(tiling.tile / 16) * static_cast<uint32_t>(tiling.tile / 16);
+    const uint32_t nb = static_cast<uint32_t>(per_rank) * bpt;
+    DevCamera dc; to_dev_camera(*cam, dc);
+    RT_HIP(rt_launch_render(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, max_scatters, min_scatter_intensity,
+                            rgb_dev, nullptr, ctx->d_ctr));
+    return RT_OK;
+}
+
+int rt_assemble_tiles(rt_ctx* ctx, rt_tiling tiling, const uint8_t* gathered_dev, uint8_t* frame_rgb_dev) {
+    if (int rc = use(ctx)) return rc;
+    if (!gathered_dev || !frame_rgb_dev) return fail(RT_ERR_INVALID, "null argument");
+    if (int rc = tiling_ok(tiling)) return rc;
+    RT_HIP(rt_launch_assemble(ctx->stream, tiling.width, tiling.height, tiling.tile, (tiling.width + tiling.tile - 1) / tiling.tile,
+                              tiling.n_ranks, rt_tiles_per_rank(tiling), gathered_dev, frame_rgb_dev));
+    return RT_OK;
+}
+
+// ---- host-memory conveniences ---------------------------------------------------------------------
+
+int rt_render_frame_host(rt_ctx* ctx, const rt_camera* cam, int max_scatters, double min_scatter_intensity,
+                         uint8_t* rgb_host, int32_t* hit_id_host) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !rgb_host) return fail(RT_ERR_INVALID, "bad camera or null output");
+    const size_t px = static_cast<size_t>(cam->width) * cam->height;
+    void *d_rgb = nullptr, *d_ids = nullptr;
+    if (int rc = ctx->need(0, px * 3, &d_rgb)) return rc;
+    if (hit_id_host) if (int rc = ctx->need(1, px * sizeof(int32_t), &d_ids)) return rc;
+    const rt_rect full = { 0, 0, cam->width, cam->height };
+    if (int rc = rt_render_rect(ctx, cam, full, max_scatters, min_scatter_intensity, static_cast<uint8_t*>(d_rgb), static_cast<int32_t*>(d_ids))) return rc;
+    RT_HIP(hipMemcpyAsync(rgb_host, d_rgb, px * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (hit_id_host) RT_HIP(hipMemcpyAsync(hit_id_host, d_ids, px * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace_primary_host(rt_ctx* ctx, const rt_camera* cam, int32_t* hit_id_host, double* dist_host) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam)) return fail(RT_ERR_INVALID, "bad camera");
+    const size_t px = static_cast<size_t>(cam->width) * cam->height;
+    void *d_ids = nullptr, *d_dist = nullptr;
+    if (int rc = ctx->need(1, px * sizeof(int32_t), &d_ids)) return rc;
+    if (int rc = ctx->need(2, px * sizeof(double), &d_dist)) return rc;
+    const rt_rect full = { 0, 0, cam->width, cam->height };
+    if (int rc = rt_trace_primary(ctx, cam, full, static_cast<int32_t*>(d_ids), static_cast<double*>(d_dist))) return rc;
+    if (hit_id_host) RT_HIP(hipMemcpyAsync(hit_id_host, d_ids, px * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (dist_host) RT_HIP(hipMemcpyAsync(dist_host, d_dist, px * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace_rays_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, int32_t* hit_id_host, double* dist_host) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n == 0) return RT_OK;
+    if (!rays6_host) return fail(RT_ERR_INVALID, "null rays");
+    void *d_rays = nullptr, *d_ids = nullptr, *d_dist = nullptr;
+    if (int rc = ctx->need(0, n * 6 * sizeof(double), &d_rays)) return rc;
+    if (int rc = ctx->need(1, n * sizeof(int32_t), &d_ids)) return rc;
+    if (int rc = ctx->need(2, n * sizeof(double), &d_dist)) return rc;
+    RT_HIP(hipMemcpyAsync(d_rays, rays6_host, n * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rt_trace_rays(ctx, static_cast<const double*>(d_rays), n, static_cast<int32_t*>(d_ids), static_cast<double*>(d_dist))) return rc;
+    if (hit_id_host) RT_HIP(hipMemcpyAsync(hit_id_host, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (dist_host) RT_HIP(hipMemcpyAsync(dist_host, d_dist, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// ---- misc ---------------------------------------------------------------------------------------
+
+const char* rt_strerror(int status) {
+    switch (status) {
+        case RT_OK: return "ok";
+        case RT_ERR_INVALID: return "invalid argument";
+        case RT_ERR_IO: return "cannot read file";
+        case RT_ERR_NOT_FOUND: return "not found";
+        case RT_ERR_NO_DEVICE: return "no usable GPU";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_NO_SCENE: return "no scene uploaded";
+        case RT_ERR_LIMIT: return "limit exceeded";
+        case RT_ERR_PARSE: return "malformed number in scene file";
+        default: return "unknown status";
+    }
+}
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+} // extern "C"

@@ -1,0 +1,49 @@
+// Kernel argument blocks and launcher prototypes shared by rt_kernels.hip and rt_capi.cpp.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include "rt_internal.h"
+
+#define RT_BLOCK 256               // threads per block: 4 waves, one 16x16 pixel region
+
+struct DevScene {
+    const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
+    const rt_prim_rec* recs;       // BVH slot order, loose primitives after n_slots
+    const rt_mat_rec*  mats;       // by primitive id
+    const rt_light*    lights;
+    const uint8_t*     gamma;      // 256-entry table
+    uint32_t n_nodes, n_slots, n_loose, n_lights;
+    float radius;                  // max |coordinate| of the scene: scales the box padding
+};
+
+struct DevCamera {                 // persp_camera.h:29-36 with the sensor-fit branch already taken
+    double pos[3];
+    double rot[9];
+    double eff_w, eff_h, focal;
+    double width, height;
+};
+
+// How blocks map to pixels and output slots.
+//   mode 0: rectangle (x0, y0, w, h) of the frame, output row-major in the rectangle;
+//           super_x = 8x8-block super tiles per row.
+//   mode 1: this rank's tiles of a tiled frame (w, h = frame size, x0 = y0 = 0); output tile after tile.
+struct PixelMap {
+    int mode;
+    int x0, y0, w, h;
+    uint32_t super_x;
+    int tile, tiles_x, n_tiles, rank, n_ranks;
+};
+
+extern "C" {
+hipError_t rt_launch_trace_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
+                                   uint32_t n_blocks, int counting, int32_t* ids, double* dist, rt_counters* ctr);
+hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
+                                int32_t* ids, double* dist, uint8_t* rgb, rt_counters* ctr);
+hipError_t rt_launch_render(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_blocks,
+                            int counting, int max_scatters, double min_si, uint8_t* rgb, int32_t* ids, rt_counters* ctr);
+hipError_t rt_launch_assemble(hipStream_t st, int width, int height, int tile, int tiles_x, int n_ranks, int tiles_per_rank,
+                              const uint8_t* gathered, uint8_t* frame);
+}
+
+#endif

@@ -1,0 +1,40 @@
+// Internal layouts shared by the host-side scene builder and the HIP kernels.
+#ifndef RT_INTERNAL_H
+#define RT_INTERNAL_H
+
+#include <stdint.h>
+#include "rt_hip.h"
+
+// Flattened primitive record, 160 bytes, read by the kernels with 16-byte loads.
+//   cube / cylinder : d[0..2] T, d[3..11] R row-major, d[12..14] S, d[15..17] 1/S (0 where S == 0)
+//   sphere          : d[0..2] C, d[3..5] S, d[6..8] 1/S
+//   plane / triangle: d[0..8] inverse of [e1 e2 n] row-major, d[9..11] P0, d[12..14] e1, d[15..17] e2
+// All derived values are computed on the host with the reference's operation order
+// (s2899221/Code/mesh.cpp:122-145, 176-178, 803-847) so the device never evaluates sin/cos.
+struct rt_prim_rec {
+    double   d[18];
+    uint32_t kind;
+    uint32_t id;        // index in the caller's primitive list (reference id order)
+    uint32_t pad[2];
+};
+
+// Per-primitive shading inputs, indexed by id: Mesh material getters + solid evaluate_albedo
+// (s2899221/Code/mesh.h:36-59, mesh.cpp:15-45).
+struct rt_mat_rec {
+    double  metallic, roughness, ior;
+    uint8_t albedo[3];
+    uint8_t pad[5];
+};
+
+#define RT_STACK_DEPTH 32          // traversal stack entries per lane; the builder keeps depth <= 31
+#define RT_MAX_SCATTERS 8
+#define RT_PAD_SHIFT 18            // FP32 box padding = 2^-18 * max(|ray origin|, scene radius)
+
+#ifdef __cplusplus
+static_assert(sizeof(rt_prim_rec) == 160, "record layout");
+static_assert(sizeof(rt_mat_rec) == 32, "material layout");
+static_assert(sizeof(rt_node32) == 32, "node layout");
+static_assert(sizeof(rt_prim_desc) == 160, "description layout");
+#endif
+
+#endif
