@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mrays/s (primary + shadow) at 3840x2160 on the 1M-cell mixed-primitive scene.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one full frame through the hot path (primary rays, closest hit, one shadow ray per light per
+hit, Blinn-Phong, gamma) with the scene already resident in HBM.  With N > 1 the SAME frame is split into
+64x64 tiles dealt round-robin over the ranks (scene replicated), each rank renders its tiles, the tiles are
+gathered to rank 0 over RCCL and scattered into the frame there; that gather + assembly is inside the timed
+region, so per-N values are strong scaling of one frame.
+
+Ray count per frame = W*H primary + (#primary hits) * (#lights) shadow rays, exactly as the reference casts
+them (s2899221/Code/raytracer.cpp:210-240).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+NODE_BYTES, PRIM_BYTES = 32, 64
+
+
+def algorithmic_bytes(c):
+    """Per-frame algorithmic traffic: 32 B per BVH node fetched, 64 B per primitive record fetched, 8 B written
+    per primary ray ({hit id, t}), 8 B read + 1 B written per shadow ray."""
+    return (NODE_BYTES * (c["nodes_primary"] + c["nodes_shadow"]) + PRIM_BYTES * (c["prims_primary"] + c["prims_shadow"])
+            + 8 * c["primary_rays"] + 9 * c["shadow_rays"])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(scene, prims, lights, camd, budget_s, threads):
+    """The CPU restatement (oracle, "port") walking the same flattened BVH on a strided pixel sample of the same
+    frame, all requested host threads (OpenMP over rows).  Returns the bench JSON object and the sampled counts."""
+    from oracle import bind
+    O = bind.Oracle()
+    osc = O.scene(prims, lights)
+    nodes, slots, n_slots, n_loose, radius = scene.bvh()
+    bvh = O.bvh(nodes, slots, n_slots, n_loose, radius)
+    cam = bind.camera_from_dict(O, camd)
+    W, H = camd["res"]
+    threads = threads or min(os.cpu_count() or 1, 16)
+    # calibrate on a coarse grid, then pick the stride that fills the budget
+    t0 = time.perf_counter()
+    _, _, counts, hits = O.bvh_render(osc, bvh, cam, step=16, threads=threads)
+    dt = time.perf_counter() - t0
+    n_cal = ((W + 15) // 16) * ((H + 15) // 16)
+    per_px = dt / max(n_cal, 1)
+    step = max(1, int(np.ceil(np.sqrt(W * H * per_px / max(budget_s, 1e-3)))))
+    t0 = time.perf_counter()
+    _, _, counts, hits = O.bvh_render(osc, bvh, cam, step=step, threads=threads)
+    dt = time.perf_counter() - t0
+    n_px = ((W + step - 1) // step) * ((H + step - 1) // step)
+    rays = n_px + hits * len(lights)
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "every %dth pixel in x and y of the same frame (%d primary + %d shadow rays, %.1f s), "
+                  "FP64 C restatement through the same flattened BVH, OpenMP x%d, CPU: %s"
+                  % (step, n_px, hits * len(lights), dt, threads, cpu_model()),
+        "nodes_per_primary_ray": counts[0] / max(n_px, 1), "prims_per_primary_ray": counts[1] / max(n_px, 1),
+        "nodes_per_shadow_ray": counts[2] / max(hits * len(lights), 1), "prims_per_shadow_ray": counts[3] / max(hits * len(lights), 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-side", type=int, default=1000, help="cells per side of the primitive grid (1000 -> 1M cells)")
+    ap.add_argument("--res", default="3840x2160")
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--max-leaf", type=int, default=0)
+    ap.add_argument("--max-scatters", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 disables it)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from raytracer_amd import capi
+    from raytracer_amd import scenes as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = (int(v) for v in args.res.lower().split("x"))
+    half = args.n_side / 2.0
+    prims = S.mixed_field(n_side=args.n_side, seed=0x100000)
+    lights = S.mixed_field_lights(half_extent=half, height=120.0 * half / 500.0, intensity=4000.0 * (half / 500.0) ** 2)
+    camd = S.mixed_field_camera(half_extent=half, res=(W, H))
+    t0 = time.perf_counter()
+    scene = capi.Scene.create(prims, lights, max_leaf=args.max_leaf)
+    build_s = time.perf_counter() - t0
+    info = scene.info()
+    cam = capi.make_camera(**camd)
+
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload(scene)
+
+    tiling = capi.Tiling(W, H, args.tile, world)
+    if world == 1:
+        frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
+        def step():
+            ctx.render_rect_dev(cam, (0, 0, W, H), frame.data_ptr(), None, args.max_scatters, 0.0)
+    else:
+        per_rank = capi.tiles_per_rank(tiling) * args.tile * args.tile * 3
+        local = torch.empty(per_rank, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(world * per_rank, dtype=torch.uint8, device="cuda") if rank == 0 else None
+        frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda") if rank == 0 else None
+        glist = list(gathered.split(per_rank)) if rank == 0 else None
+        def step():
+            ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
+            dist.gather(local, glist, dst=0)
+            if rank == 0:
+                ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ray counts and algorithmic traffic of one frame: one untimed pass through the counting kernels
+    ctx.set_counting(True)
+    ctx.reset_counters()
+    step()
+    torch.cuda.synchronize()
+    c = ctx.counters()
+    ctx.set_counting(False)
+    keys = sorted(c)
+    tot = torch.tensor([c[k] for k in keys], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tot)
+    total = dict(zip(keys, (int(v) for v in tot.tolist())))
+    my_bytes = algorithmic_bytes(c)
+    rays_per_frame = total["primary_rays"] + total["shadow_rays"] + total["bounce_rays"]
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)          # brackets the render launch only (the dominant kernel) on its own stream
+        if world == 1:
+            step()
+            b.record(stream)
+        else:
+            ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
+            b.record(stream)
+            dist.gather(local, glist, dst=0)
+            if rank == 0:
+                ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = (float(v) for v in t.tolist())
+
+    if rank == 0:
+        achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/sec (primary+shadow) at %dx%d" % (W, H),
+            "value": rays_per_frame * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64 leaf tests + f32 box tests",
+            "data": "synthetic",
+            "config": {
+                "workload": "1M-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
+                            % (W, H, len(lights)),
+                "n_side": args.n_side, "n_prims": int(info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
+                "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
+                "partition": "image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world if world > 1 else "single GPU",
+                "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
+                "shadow_rays": total["shadow_rays"], "scene_build_s": round(build_s, 3),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "k_render<false,%s>" % ("true" if args.max_scatters > 0 else "false"),
+                "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                "algorithmic_bytes_per_launch": my_bytes,
+                "nodes_per_primary_ray": c["nodes_primary"] / max(c["primary_rays"], 1),
+                "prims_per_primary_ray": c["prims_primary"] / max(c["primary_rays"], 1),
+                "nodes_per_shadow_ray": c["nodes_shadow"] / max(c["shadow_rays"], 1),
+                "prims_per_shadow_ray": c["prims_shadow"] / max(c["shadow_rays"], 1),
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(scene, prims, lights, camd, args.cpu_seconds, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

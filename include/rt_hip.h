@@ -132,9 +132,11 @@ int rt_camera_pixel_to_ray(const rt_camera* cam, double px, double py, double or
 
 int rt_ctx_create(int device, rt_ctx** out);
 int rt_ctx_destroy(rt_ctx* ctx);
-/* Launch on the caller's stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL = the
- * context's own stream. */
+/* Launch on the caller's stream: a hipStream_t such as torch.cuda.current_stream().cuda_stream, where NULL is
+ * HIP's default stream (torch's default).  A fresh context launches on a private non-blocking stream;
+ * rt_ctx_use_own_stream returns to it. */
 int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
+int rt_ctx_use_own_stream(rt_ctx* ctx);
 int rt_ctx_synchronize(rt_ctx* ctx);
 /* Copy the scene to the context's GPU (synchronous; replaces a previously uploaded scene). */
 int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene);

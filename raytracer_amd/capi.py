@@ -76,6 +76,7 @@ SYMBOLS = [
     ("rt_ctx_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
     ("rt_ctx_destroy", C.c_int, [_VP]),
     ("rt_ctx_set_stream", C.c_int, [_VP, _VP]),
+    ("rt_ctx_use_own_stream", C.c_int, [_VP]),
     ("rt_ctx_synchronize", C.c_int, [_VP]),
     ("rt_scene_upload", C.c_int, [_VP, _VP]),
     ("rt_trace_primary", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP, _VP]),
@@ -107,6 +108,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("librt_hip.so is not built (%s): run `python -m raytracer_amd.build`" % LIB_PATH)
+        # A process must hold ONE HIP runtime.  torch wheels bundle their own libamdhip64.so.7 and look it up by
+        # file name, so if the system copy is loaded first torch loads a second runtime and finds no GPU.  Loading
+        # torch first makes librt_hip.so bind to torch's copy (same SONAME), which also makes torch's streams and
+        # events valid handles for this library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
@@ -261,7 +270,11 @@ class Context:
             pass
 
     def set_stream(self, hip_stream):
+        """hip_stream: integer handle (0 = HIP's default stream, which is torch's default stream)."""
         _check(lib().rt_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def use_own_stream(self):
+        _check(lib().rt_ctx_use_own_stream(self.h))
 
     def synchronize(self):
         _check(lib().rt_ctx_synchronize(self.h))

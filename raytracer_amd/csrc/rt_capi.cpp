@@ -253,7 +253,13 @@ int rt_ctx_destroy(rt_ctx* ctx) {
 
 int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return RT_OK;
+}
+
+int rt_ctx_use_own_stream(rt_ctx* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->stream = ctx->own_stream;
     return RT_OK;
 }
 

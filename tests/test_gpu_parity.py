@@ -113,3 +113,193 @@ def test_triangles_against_reference_planes(ctx):
     assert np.array_equal(mapped, g["ids"].astype(np.int32))
     hit = g["ids"] >= 0
     assert (np.abs(tdist[hit] - g["dist"][hit]) / g["dist"][hit]).max() < 1e-12
+
+
+def oracle_bvh(oracle, sc):
+    nodes, slots, n_slots, n_loose, radius = sc.bvh()
+    return oracle.bvh(nodes, slots, n_slots, n_loose, radius)
+
+
+def ocamera(cam):
+    from oracle import bind
+    return bind.Camera.from_buffer_copy(bytes(cam))
+
+
+def test_loose_degenerate_and_tied_primitives(ctx, oracle):
+    prims, lights, camd = S.random_scene(40, 31, lights=2)
+    extra = S.new_prims(8)
+    extra["kind"] = [S.CUBE, S.SPHERE, S.PLANE, S.PLANE, S.SPHERE, S.SPHERE, S.CYLINDER, S.PLANE]
+    extra["q"][0, :9] = [0.5, 0.2, 0.1, 0.3, 0.2, 0.1, 0.0, 0.7, 0.4]
+    extra["q"][1, :6] = [-1.0, 0.5, 0.3, 0.6, 0.0, 0.5]
+    extra["q"][2, :12] = [0, 0, 0, 1, 1, 1, 5, 5, 5, 2, 2, 2]
+    extra["q"][3, :12] = [0, 0, 1, 1, 0, 1, 0, 0, 0, 0, 0, 0]; extra["reserved"][3] = 1
+    extra["q"][4, :6] = [1.0, -1.0, 0.5, 0.8, 0.8, 0.8]
+    extra["q"][5, :6] = [1.0, -1.0, 0.5, 0.8, 0.8, 0.8]
+    extra["q"][6, :9] = [-2.0, 1.0, 0.0, 0.4, 1.0, 2.0, 0.5, 0.5, 1.5]
+    extra["q"][7, :12] = [-3, -3, -1.5, 3, -3, -1.5, 9, 9, 4, -3, 3, -1.5]
+    allp = S.sort_reference_order(np.concatenate([prims, extra]))
+    sc = capi.Scene.create(allp, lights)
+    assert sc.info().n_loose == 2
+    ctx.upload(sc)
+    cam = capi.make_camera(**camd)
+    osc = oracle.scene(allp, lights)
+    want_ids, want_dist = oracle.trace_primary(osc, ocamera(cam))
+    ids, dist = ctx.trace_primary(cam)
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(bits(dist), bits(want_dist))
+    for ms in (0, 2):
+        want_rgb, _, _ = oracle.render(osc, ocamera(cam), max_scatters=ms)
+        assert_rgb_close(ctx.render(cam, max_scatters=ms), want_rgb, max_frac=1e-3)
+    rng = np.random.default_rng(9)
+    o = rng.uniform(-4, 4, size=(20000, 3))
+    d = rng.normal(size=(20000, 3)) * rng.uniform(0.01, 30, size=(20000, 1))
+    d[:50, 0] = 0.0
+    d[50:100, 1:] = 0.0
+    d[100] = 0.0
+    rays = np.concatenate([o, d], axis=1)
+    a = oracle.trace_rays(osc, rays)
+    ids, dist = ctx.trace_rays(rays)
+    assert np.array_equal(ids, a["id"])
+    assert np.array_equal(bits(dist), bits(a["dist"]))
+
+
+def test_empty_and_single_primitive_scenes(ctx, oracle):
+    cam = capi.make_camera([0, -5, 1], [0, 1, -0.1], res=(64, 48))
+    lights = np.zeros(1, S.LIGHT_DT); lights["pos"] = [2, -3, 4]; lights["intensity"] = 30.0
+    ctx.upload(capi.Scene.create(S.new_prims(0), lights))
+    ids, dist = ctx.trace_primary(cam)
+    assert (ids == -1).all() and np.isinf(dist).all()
+    assert not ctx.render(cam, max_scatters=2).any()
+    one = S.new_prims(1); one["kind"] = S.SPHERE; one["q"][0, :6] = [0, 0, 0.5, 1, 1.5, 0.7]
+    ctx.upload(capi.Scene.create(one, lights))
+    osc = oracle.scene(one, lights)
+    want_ids, want_dist = oracle.trace_primary(osc, ocamera(cam))
+    ids, dist = ctx.trace_primary(cam)
+    assert np.array_equal(ids, want_ids) and np.array_equal(bits(dist), bits(want_dist))
+    want_rgb, _, _ = oracle.render(osc, ocamera(cam), max_scatters=2)
+    assert_rgb_close(ctx.render(cam, max_scatters=2), want_rgb, max_frac=1e-3)
+
+
+def test_counting_kernels_match_the_cpu_walk(ctx, oracle):
+    """Node / primitive fetch counts (V_n, V_p of the roofline accounting) from the instrumented kernels equal the
+    CPU restatement's walk of the same flattened BVH, ray class by ray class."""
+    prims = S.mixed_field(n_side=30, seed=77)
+    lights = S.mixed_field_lights(half_extent=15.0, height=8.0, intensity=60.0)
+    cam = capi.make_camera(**S.mixed_field_camera(half_extent=15.0, res=(200, 120)))
+    for max_leaf in (1, 2):
+        sc = capi.Scene.create(prims, lights, max_leaf=max_leaf)
+        ctx.upload(sc)
+        ctx.set_counting(True)
+        ctx.reset_counters()
+        rgb, ids = ctx.render(cam, max_scatters=0, want_ids=True)
+        c = ctx.counters()
+        ctx.set_counting(False)
+        want_ids, want_rgb, counts, hits = oracle.bvh_render(oracle.scene(prims, lights), oracle_bvh(oracle, sc), ocamera(cam))
+        assert np.array_equal(ids, want_ids)
+        assert_rgb_close(rgb, want_rgb, max_frac=1e-3)
+        assert c["primary_hits"] == hits and c["shadow_rays"] == hits * 4
+        assert [c["nodes_primary"], c["prims_primary"], c["nodes_shadow"], c["prims_shadow"]] == list(counts)
+        # the plain kernels give the same picture and leave the fetch counters alone
+        ctx.reset_counters()
+        rgb2 = ctx.render(cam, max_scatters=0)
+        c2 = ctx.counters()
+        assert np.array_equal(rgb, rgb2) and c2["nodes_primary"] == 0 and c2["primary_hits"] == hits
+
+
+def test_tiles_and_subrectangles(ctx):
+    """Multi-GPU partition exercised on one GPU with virtual ranks: rendering every rank's tiles and assembling
+    them reproduces the single-launch frame byte for byte; so does a sub-rectangle."""
+    import torch
+    prims, lights, camd = S.random_scene(80, 5, lights=2)
+    camd = dict(camd, res=(200, 136))          # not a multiple of the tile size
+    cam = capi.make_camera(**camd)
+    ctx.upload(capi.Scene.create(prims, lights))
+    W, H = camd["res"]
+    for ms in (0, 1):
+        full = ctx.render(cam, max_scatters=ms)
+        for tile, n_ranks in ((16, 1), (32, 2), (64, 3), (48, 8)):
+            tiling = capi.Tiling(W, H, tile, n_ranks)
+            per = capi.tiles_per_rank(tiling) * tile * tile * 3
+            assert capi.tile_count(tiling) == ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
+            gathered = torch.full((n_ranks * per,), 7, dtype=torch.uint8, device="cuda")
+            for r in range(n_ranks):
+                ctx.render_tiles_dev(cam, tiling, r, gathered.data_ptr() + r * per, ms, 0.0)
+            frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
+            ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+            ctx.synchronize()
+            assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), full), (tile, n_ranks)
+        x0, y0, w, h = 37, 21, 101, 77
+        sub = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda")
+        sid = torch.empty(h * w, dtype=torch.int32, device="cuda")
+        ctx.render_rect_dev(cam, (x0, y0, w, h), sub.data_ptr(), sid.data_ptr(), ms, 0.0)
+        ctx.synchronize()
+        assert np.array_equal(sub.cpu().numpy().reshape(h, w, 3), full[y0:y0 + h, x0:x0 + w])
+    ids, _ = ctx.trace_primary(cam)
+    assert np.array_equal(sid.cpu().numpy().reshape(h, w), ids[y0:y0 + h, x0:x0 + w])
+
+
+def test_callers_stream_and_device_pointers(ctx):
+    import torch
+    prims, lights, camd = S.random_scene(30, 8, lights=1)
+    cam = capi.make_camera(**camd)
+    ctx.upload(capi.Scene.create(prims, lights))
+    W, H = camd["res"]
+    want_ids, want_dist = ctx.trace_primary(cam)
+    s = torch.cuda.Stream()
+    try:
+        ctx.set_stream(s.cuda_stream)
+        with torch.cuda.stream(s):
+            ids = torch.empty(H * W, dtype=torch.int32, device="cuda")
+            dist = torch.empty(H * W, dtype=torch.float64, device="cuda")
+            ctx.trace_primary_dev(cam, (0, 0, W, H), ids.data_ptr(), dist.data_ptr())
+            rays = torch.from_numpy(capi.pixel_rays(cam, [[10.5, 20.5], [80.5, 45.5]])).cuda()
+            rid = torch.empty(2, dtype=torch.int32, device="cuda")
+            rgb = torch.empty(6, dtype=torch.uint8, device="cuda")
+            ctx.trace_rays_dev(rays.data_ptr(), 2, rid.data_ptr(), None)
+            ctx.shade_rays_dev(rays.data_ptr(), 2, rgb.data_ptr())
+        s.synchronize()
+        assert np.array_equal(ids.cpu().numpy().reshape(H, W), want_ids)
+        assert np.array_equal(bits(dist.cpu().numpy().reshape(H, W)), bits(want_dist))
+        assert rid.cpu().tolist() == [int(want_ids[20, 10]), int(want_ids[45, 80])]
+    finally:
+        ctx.use_own_stream()
+
+
+def test_shade_rays_against_oracle(ctx, oracle):
+    g = np.load(os.path.join(GOLDEN, "shipped_Test2.npz"))
+    import torch
+    sc = capi.Scene.load_json(os.path.join(SCENES, "Test2.json"))
+    cam, _ = sc.camera("142")
+    ctx.upload(sc)
+    ys, xs = np.mgrid[0:270:3, 0:480:3]
+    rays = capi.pixel_rays(cam, np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], axis=1))
+    d_rays = torch.from_numpy(rays).cuda()
+    rgb = torch.empty(len(rays) * 3, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(0)
+    try:
+        ctx.shade_rays_dev(d_rays.data_ptr(), len(rays), rgb.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
+    assert_rgb_close(rgb.cpu().numpy().reshape(-1, 3)[None], g["shade_linear"][::3, ::3].reshape(-1, 3)[None], max_frac=1e-3)
+
+
+def test_error_statuses_on_device():
+    c = capi.Context(0)
+    cam = capi.make_camera([0, -5, 1], [0, 1, 0], res=(32, 32))
+    with pytest.raises(capi.RtError) as e:
+        c.trace_primary(cam)
+    assert e.value.status == -6
+    c.upload(capi.Scene.create(S.random_scene(5, 1)[0], S.random_scene(5, 1)[1]))
+    import torch
+    buf = torch.empty(32 * 32 * 3, dtype=torch.uint8, device="cuda")
+    with pytest.raises(capi.RtError) as e:
+        c.render_rect_dev(cam, (0, 0, 33, 32), buf.data_ptr())
+    assert e.value.status == -1
+    with pytest.raises(capi.RtError) as e:
+        c.render_rect_dev(cam, (0, 0, 32, 32), buf.data_ptr(), None, 9)
+    assert e.value.status == -7
+    with pytest.raises(capi.RtError) as e:
+        c.render_tiles_dev(cam, capi.Tiling(32, 32, 24, 2), 0, buf.data_ptr())
+    assert e.value.status == -1
+    c.close()
