@@ -746,35 +746,42 @@ static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int 
     hit_clear(&w.best); w.found_mid = 0; w.vp = 0;
     w.limit = (mode == 0) ? RTO_INF : (light_dist - 1e-4);   /* only hits with dist < limit matter */
     w.limit_f = f32_up(w.limit);
-    uint32_t stack[RTO_STACK]; int sp = 0;
+    /* The stack keeps, for every postponed child, its (first, count) and its box entry distance: a pop needs
+     * no memory access and drops entries that now start beyond the search limit.  Node records fetched: the
+     * root once, then both children of every internal node visited. */
+    struct { uint32_t first, count; float t; } stack[RTO_STACK];
+    int sp = 0;
     int64_t vn = 0;
     int closed = 0;
 
     if (B->n_nodes > 0) {
-        rto_node32 cur = B->nodes[0]; vn += 1;
-        int have = (box_entry(&cur, &br, w.limit_f) != __builtin_inff());
+        const rto_node32 root = B->nodes[0]; vn += 1;
+        int have = (box_entry(&root, &br, w.limit_f) != __builtin_inff());
+        uint32_t first = root.first, count = root.count;
         for (;;) {
             if (have) {
-                if (cur.count > 0) {
-                    for (uint32_t s = 0; s < cur.count && !closed; ++s) closed = walk_slot(&w, cur.first + s);
+                if (count > 0) {
+                    for (uint32_t s = 0; s < count && !closed; ++s) closed = walk_slot(&w, first + s);
                     if (closed) break;
                     have = 0;
                 } else {
-                    const rto_node32 l = B->nodes[cur.first], r = B->nodes[cur.first + 1]; vn += 2;
+                    const rto_node32 l = B->nodes[first], r = B->nodes[first + 1]; vn += 2;
                     const float tl = box_entry(&l, &br, w.limit_f), tr = box_entry(&r, &br, w.limit_f);
                     const int hl = tl != __builtin_inff(), hr = tr != __builtin_inff();
                     if (hl && hr) {
-                        if (tr < tl) { stack[sp++] = cur.first;     cur = r; }
-                        else         { stack[sp++] = cur.first + 1; cur = l; }
-                    } else if (hl) cur = l;
-                    else if (hr) cur = r;
+                        if (tr < tl) { stack[sp].first = l.first; stack[sp].count = l.count; stack[sp].t = tl; ++sp; first = r.first; count = r.count; }
+                        else         { stack[sp].first = r.first; stack[sp].count = r.count; stack[sp].t = tr; ++sp; first = l.first; count = l.count; }
+                    } else if (hl) { first = l.first; count = l.count; }
+                    else if (hr)   { first = r.first; count = r.count; }
                     else have = 0;
                 }
             }
             if (!have) {
-                if (sp == 0) break;
-                cur = B->nodes[stack[--sp]]; vn += 1;
-                have = (box_entry(&cur, &br, w.limit_f) != __builtin_inff());
+                while (sp > 0 && !have) {
+                    --sp;
+                    if (stack[sp].t <= w.limit_f) { first = stack[sp].first; count = stack[sp].count; have = 1; }
+                }
+                if (!have) break;
             }
         }
     }

@@ -23,6 +23,9 @@ int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
             return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+constexpr size_t kCounterBytes = static_cast<size_t>(RT_CTR_SHARDS) * RT_CTR_STRIDE * sizeof(uint64_t);
+static_assert(sizeof(rt_counters) == 8 * sizeof(uint64_t), "counter block");
+
 template <class T> int upload(const std::vector<T>& v, T** dev) {
     *dev = nullptr;
     if (v.empty()) return RT_OK;
@@ -43,8 +46,8 @@ struct rt_ctx {
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; uint8_t* d_gamma = nullptr; rt_counters* d_ctr = nullptr;
     // grow-only scratch of the *_host conveniences
-    void* scratch[3] = { nullptr, nullptr, nullptr };
-    size_t scratch_bytes[3] = { 0, 0, 0 };
+    void* scratch[4] = { nullptr, nullptr, nullptr, nullptr };    // 0..2 host conveniences, 3 frame working set
+    size_t scratch_bytes[4] = { 0, 0, 0, 0 };
 
     void free_scene() {
         if (d_nodes) (void)hipFree(d_nodes);
@@ -89,11 +92,10 @@ int rect_map(const rt_camera* cam, rt_rect r, PixelMap& pm, uint32_t& n_blocks) 
         return fail(RT_ERR_INVALID, "rectangle outside the camera's film resolution");
     std::memset(&pm, 0, sizeof(pm));
     pm.mode = 0; pm.x0 = r.x0; pm.y0 = r.y0; pm.w = r.w; pm.h = r.h;
-    const uint32_t bx = (static_cast<uint32_t>(r.w) + 15u) / 16u, by = (static_cast<uint32_t>(r.h) + 15u) / 16u;
-    pm.super_x = (bx + 7u) / 8u;
-    const uint64_t nb = static_cast<uint64_t>(pm.super_x) * ((by + 7u) / 8u) * 64u;
-    if (nb > 0x7FFFFFFFull) return fail(RT_ERR_LIMIT, "rectangle too large for one launch");
-    n_blocks = static_cast<uint32_t>(nb);
+    pm.super_x = (static_cast<uint32_t>(r.w) + 127u) / 128u;
+    const uint64_t nb = static_cast<uint64_t>(pm.super_x) * ((static_cast<uint32_t>(r.h) + 127u) / 128u) * 256u;
+    if (nb > 0x0FFFFFFFull) return fail(RT_ERR_LIMIT, "rectangle too large for one launch");
+    n_blocks = static_cast<uint32_t>(nb);      // waves: one 8x8 tile each
     return RT_OK;
 }
 
@@ -224,8 +226,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
     c->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_ctr), sizeof(rt_counters));
-    if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(rt_counters));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_ctr), kCounterBytes);
+    if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, kCounterBytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 256);
     if (e == hipSuccess) { uint8_t lut[256]; rt_gamma_table(lut); e = hipMemcpy(c->d_gamma, lut, 256, hipMemcpyHostToDevice); }
     if (e != hipSuccess) {
@@ -276,15 +278,21 @@ int rt_ctx_set_counting(rt_ctx* ctx, int on) {
 
 int rt_counters_reset(rt_ctx* ctx) {
     if (int rc = use(ctx)) return rc;
-    RT_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(rt_counters), ctx->stream));
+    RT_HIP(hipMemsetAsync(ctx->d_ctr, 0, kCounterBytes, ctx->stream));
     return RT_OK;
 }
 
 int rt_counters_read(rt_ctx* ctx, rt_counters* out) {
     if (!out) return fail(RT_ERR_INVALID, "null argument");
     if (int rc = use(ctx)) return rc;
-    RT_HIP(hipMemcpyAsync(out, ctx->d_ctr, sizeof(rt_counters), hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t raw[RT_CTR_SHARDS * RT_CTR_STRIDE];
+    RT_HIP(hipMemcpyAsync(raw, ctx->d_ctr, kCounterBytes, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t* o = reinterpret_cast<uint64_t*>(out);
+    for (int f = 0; f < 8; ++f) {
+        o[f] = 0;
+        for (int s = 0; s < RT_CTR_SHARDS; ++s) o[f] += raw[s * RT_CTR_STRIDE + f];
+    }
     return RT_OK;
 }
 
@@ -313,20 +321,55 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
 
 // ---- launches ------------------------------------------------------------------------------------
 
+namespace {
+
+// Carve the frame working set out of the context's grow-only scratch (allocated on first use of a size).
+int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
+    const size_t planes = 7 + n_batch;
+    void* base = nullptr;
+    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t)) + 256, &base)) return rc;
+    double* d = static_cast<double*>(base);
+    fb.px = d; fb.py = d + n; fb.pz = d + 2*n; fb.nx = d + 3*n; fb.ny = d + 4*n; fb.nz = d + 5*n;
+    fb.lighting = d + 6*n; fb.contrib = d + 7*n;
+    fb.id = reinterpret_cast<int32_t*>(d + planes * n);
+    fb.n = n;
+    return RT_OK;
+}
+
+// Primary pass, shadow pass per light batch, resolve: the max_scatters = 0 frame.
+int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out,
+                 uint8_t* rgb_dev, int32_t* hit_id_dev) {
+    const uint32_t n_lights = ctx->sc.n_lights;
+    const uint32_t batch = n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH;
+    FrameBufs fb;
+    if (int rc = frame_bufs(ctx, n_out, batch, fb)) return rc;
+    if (pm.mode == 1)   // padded slots of edge tiles and of a short last round: no primitive
+        RT_HIP(hipMemsetAsync(fb.id, 0xFF, n_out * sizeof(int32_t), ctx->stream));
+    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, ctx->counting, hit_id_dev, nullptr, &fb, ctx->d_ctr));
+    for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
+        const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
+        RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, l0, nb, ctx->counting, &fb, ctx->d_ctr));
+        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &fb, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
+    }
+    return RT_OK;
+}
+
+} // namespace
+
 int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* hit_id_dev, double* dist_dev) {
     if (int rc = need_scene(ctx)) return rc;
     if (!camera_ok(cam)) return fail(RT_ERR_INVALID, "bad camera (resolution must be positive)");
-    PixelMap pm; uint32_t nb = 0;
-    if (int rc = rect_map(cam, rect, pm, nb)) return rc;
+    PixelMap pm; uint32_t nw = 0;
+    if (int rc = rect_map(cam, rect, pm, nw)) return rc;
     DevCamera dc; to_dev_camera(*cam, dc);
-    RT_HIP(rt_launch_trace_primary(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, hit_id_dev, dist_dev, ctx->d_ctr));
+    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, hit_id_dev, dist_dev, nullptr, ctx->d_ctr));
     return RT_OK;
 }
 
 int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit_id_dev, double* dist_dev) {
     if (int rc = need_scene(ctx)) return rc;
     if (n && !rays6_dev) return fail(RT_ERR_INVALID, "null rays");
-    if (n > 0x7FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
     RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, hit_id_dev, dist_dev, nullptr, ctx->d_ctr));
     return RT_OK;
 }
@@ -334,7 +377,7 @@ int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit
 int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb_dev) {
     if (int rc = need_scene(ctx)) return rc;
     if (n && (!rays6_dev || !rgb_dev)) return fail(RT_ERR_INVALID, "null argument");
-    if (n > 0x7FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
     RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 1, nullptr, nullptr, rgb_dev, ctx->d_ctr));
     return RT_OK;
 }
@@ -345,21 +388,23 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
     if (!camera_ok(cam) || !rgb_dev) return fail(RT_ERR_INVALID, "bad camera or null output");
     if (max_scatters < 0) max_scatters = 0;
     if (max_scatters > RT_MAX_SCATTERS) return fail(RT_ERR_LIMIT, "max_scatters above 8");
-    PixelMap pm; uint32_t nb = 0;
-    if (int rc = rect_map(cam, rect, pm, nb)) return rc;
+    PixelMap pm; uint32_t nw = 0;
+    if (int rc = rect_map(cam, rect, pm, nw)) return rc;
+    DevCamera dc; to_dev_camera(*cam, dc);
+    const size_t n_out = static_cast<size_t>(rect.w) * rect.h;
     if (ctx->sc.n_lights == 0) {
         // no lights: the reference writes an all-black frame without tracing (raytracer.cpp:387-395)
-        RT_HIP(hipMemsetAsync(rgb_dev, 0, static_cast<size_t>(rect.w) * rect.h * 3, ctx->stream));
-        if (hit_id_dev) {
-            DevCamera dc; to_dev_camera(*cam, dc);
-            RT_HIP(rt_launch_trace_primary(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, hit_id_dev, nullptr, ctx->d_ctr));
-        }
+        RT_HIP(hipMemsetAsync(rgb_dev, 0, n_out * 3, ctx->stream));
+        if (hit_id_dev)
+            RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, hit_id_dev, nullptr, nullptr, ctx->d_ctr));
         return RT_OK;
     }
-    DevCamera dc; to_dev_camera(*cam, dc);
-    RT_HIP(rt_launch_render(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, max_scatters, min_scatter_intensity,
-                            rgb_dev, hit_id_dev, ctx->d_ctr));
-    return RT_OK;
+    if (max_scatters > 0) {
+        RT_HIP(rt_launch_render_bounce(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, max_scatters, min_scatter_intensity,
+                                       rgb_dev, hit_id_dev, ctx->d_ctr));
+        return RT_OK;
+    }
+    return run_pipeline(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev);
 }
 
 int32_t rt_tile_count(rt_tiling t) {
@@ -382,20 +427,25 @@ int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int ran
     if (max_scatters < 0) max_scatters = 0;
     if (max_scatters > RT_MAX_SCATTERS) return fail(RT_ERR_LIMIT, "max_scatters above 8");
     const int32_t per_rank = rt_tiles_per_rank(tiling);
-    const size_t bytes = static_cast<size_t>(per_rank) * tiling.tile * tiling.tile * 3;
-    // padding of edge tiles and of a short last round stays zero
-    RT_HIP(hipMemsetAsync(rgb_dev, 0, bytes, ctx->stream));
-    if (ctx->sc.n_lights == 0) return RT_OK;
+    const size_t n_out = static_cast<size_t>(per_rank) * tiling.tile * tiling.tile;
     PixelMap pm; std::memset(&pm, 0, sizeof(pm));
     pm.mode = 1; pm.w = tiling.width; pm.h = tiling.height; pm.tile = tiling.tile;
     pm.tiles_x = (tiling.width + tiling.tile - 1) / tiling.tile;
     pm.n_tiles = rt_tile_count(tiling); pm.rank = rank; pm.n_ranks = tiling.n_ranks;
-    const uint32_t bpt = static_cast<uint32_t>(tiling.tile / 16) * static_cast<uint32_t>(tiling.tile / 16);
-    const uint32_t nb = static_cast<uint32_t>(per_rank) * bpt;
+    const uint32_t wpt = static_cast<uint32_t>(tiling.tile / 8) * static_cast<uint32_t>(tiling.tile / 8);
+    const uint64_t nw64 = static_cast<uint64_t>(per_rank) * wpt;
+    if (nw64 > 0x0FFFFFFFull) return fail(RT_ERR_LIMIT, "too many tiles for one launch");
+    const uint32_t nw = static_cast<uint32_t>(nw64);
     DevCamera dc; to_dev_camera(*cam, dc);
-    RT_HIP(rt_launch_render(ctx->stream, &ctx->sc, &dc, &pm, nb, ctx->counting, max_scatters, min_scatter_intensity,
-                            rgb_dev, nullptr, ctx->d_ctr));
-    return RT_OK;
+    if (ctx->sc.n_lights == 0 || max_scatters > 0) {
+        // padding of edge tiles and of a short last round stays zero
+        RT_HIP(hipMemsetAsync(rgb_dev, 0, n_out * 3, ctx->stream));
+        if (ctx->sc.n_lights == 0) return RT_OK;
+        RT_HIP(rt_launch_render_bounce(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, max_scatters, min_scatter_intensity,
+                                       rgb_dev, nullptr, ctx->d_ctr));
+        return RT_OK;
+    }
+    return run_pipeline(ctx, dc, pm, nw, n_out, rgb_dev, nullptr);
 }
 
 int rt_assemble_tiles(rt_ctx* ctx, rt_tiling tiling, const uint8_t* gathered_dev, uint8_t* frame_rgb_dev) {

@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 #include "rt_internal.h"
 
-#define RT_BLOCK 256               // threads per block: 4 waves, one 16x16 pixel region
+#define RT_STACK_LDS 16            // traversal stack entries per lane kept in LDS (8 bytes each); deeper ones go private
+#define RT_CTR_SHARDS 64           // counter replicas, one cache line each, summed on read
+#define RT_CTR_STRIDE 16           // 64-bit words between replicas (128 bytes)
+#define RT_LIGHT_BATCH 8           // lights per shadow launch (bounds the contribution planes)
 
 struct DevScene {
     const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
@@ -26,7 +29,7 @@ struct DevCamera {                 // persp_camera.h:29-36 with the sensor-fit b
 
 // How blocks map to pixels and output slots.
 //   mode 0: rectangle (x0, y0, w, h) of the frame, output row-major in the rectangle;
-//           super_x = 8x8-block super tiles per row.
+//           super_x = 128x128-pixel super tiles per row (256 waves each).
 //   mode 1: this rank's tiles of a tiled frame (w, h = frame size, x0 = y0 = 0); output tile after tile.
 struct PixelMap {
     int mode;
@@ -35,13 +38,26 @@ struct PixelMap {
     int tile, tiles_x, n_tiles, rank, n_ranks;
 };
 
+// Per-frame working set of the three-launch pipeline (all planes have n entries, indexed by output slot).
+struct FrameBufs {
+    double *px, *py, *pz;          // hit point
+    double *nx, *ny, *nz;          // unit normal, re-normalised as RayTracer::shade does
+    double *lighting;              // running light sum between light batches
+    double *contrib;               // [light in batch][n] this light's term
+    int32_t *id;                   // primary hit id, -1 = miss / padding
+    size_t n;
+};
+
 extern "C" {
-hipError_t rt_launch_trace_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
-                                   uint32_t n_blocks, int counting, int32_t* ids, double* dist, rt_counters* ctr);
+hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
+                             uint32_t n_waves, int counting, int32_t* ids, double* dist, const FrameBufs* fb, rt_counters* ctr);
+hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
+                            uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb, rt_counters* ctr);
+hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, uint32_t n_batch, int first, int last, uint8_t* rgb);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, rt_counters* ctr);
-hipError_t rt_launch_render(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_blocks,
-                            int counting, int max_scatters, double min_si, uint8_t* rgb, int32_t* ids, rt_counters* ctr);
+hipError_t rt_launch_render_bounce(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_waves,
+                                   int counting, int max_scatters, double min_si, uint8_t* rgb, int32_t* ids, rt_counters* ctr);
 hipError_t rt_launch_assemble(hipStream_t st, int width, int height, int tile, int tiles_x, int n_ranks, int tiles_per_rank,
                               const uint8_t* gathered, uint8_t* frame);
 }
