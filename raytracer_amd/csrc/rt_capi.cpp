@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,7 @@ int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
             return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+constexpr uint32_t kQueueSlots = 64;
 constexpr size_t kCounterBytes = static_cast<size_t>(RT_CTR_SHARDS) * RT_CTR_STRIDE * sizeof(uint64_t);
 static_assert(sizeof(rt_counters) == 8 * sizeof(uint64_t), "counter block");
 
@@ -45,6 +47,9 @@ struct rt_ctx {
     DevScene sc{};
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; uint8_t* d_gamma = nullptr; rt_counters* d_ctr = nullptr;
+    unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
+    uint32_t queue_used = kQueueSlots;     // slots consumed since the last zeroing
+    uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
     // grow-only scratch of the *_host conveniences
     void* scratch[4] = { nullptr, nullptr, nullptr, nullptr };    // 0..2 host conveniences, 3 frame working set
     size_t scratch_bytes[4] = { 0, 0, 0, 0 };
@@ -94,7 +99,7 @@ int rect_map(const rt_camera* cam, rt_rect r, PixelMap& pm, uint32_t& n_blocks) 
     pm.mode = 0; pm.x0 = r.x0; pm.y0 = r.y0; pm.w = r.w; pm.h = r.h;
     pm.super_x = (static_cast<uint32_t>(r.w) + 127u) / 128u;
     const uint64_t nb = static_cast<uint64_t>(pm.super_x) * ((static_cast<uint32_t>(r.h) + 127u) / 128u) * 256u;
-    if (nb > 0x0FFFFFFFull) return fail(RT_ERR_LIMIT, "rectangle too large for one launch");
+    if (nb * 64u * RT_LIGHT_BATCH >= 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rectangle too large for one launch");
     n_blocks = static_cast<uint32_t>(nb);      // waves: one 8x8 tile each
     return RT_OK;
 }
@@ -228,6 +233,16 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_ctr), kCounterBytes);
     if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, kCounterBytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_queue), kQueueSlots * sizeof(unsigned int));
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) {
+            int per_cu = 16;                                   // 4 waves per SIMD at <= 128 VGPRs
+            if (const char* env = std::getenv("RT_WAVES_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 32) per_cu = v; }
+            c->max_waves = static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu;
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 256);
     if (e == hipSuccess) { uint8_t lut[256]; rt_gamma_table(lut); e = hipMemcpy(c->d_gamma, lut, 256, hipMemcpyHostToDevice); }
     if (e != hipSuccess) {
@@ -247,6 +262,7 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     ctx->free_scene();
     if (ctx->d_ctr) (void)hipFree(ctx->d_ctr);
     if (ctx->d_gamma) (void)hipFree(ctx->d_gamma);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     for (void* p : ctx->scratch) if (p) (void)hipFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -323,6 +339,20 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
 
 namespace {
 
+// A zeroed work-queue head for the next persistent launch (the block of heads is re-zeroed when it runs out).
+int next_queue(rt_ctx* ctx, unsigned int** q) {
+    if (ctx->queue_used >= kQueueSlots) {
+        RT_HIP(hipMemsetAsync(ctx->d_queue, 0, kQueueSlots * sizeof(unsigned int), ctx->stream));
+        ctx->queue_used = 0;
+    }
+    *q = ctx->d_queue + ctx->queue_used++;
+    return RT_OK;
+}
+
+uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
+    return static_cast<uint32_t>(n_tiles < ctx->max_waves ? (n_tiles ? n_tiles : 1) : ctx->max_waves);
+}
+
 // Carve the frame working set out of the context's grow-only scratch (allocated on first use of a size).
 int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
     const size_t planes = 7 + n_batch;
@@ -345,10 +375,16 @@ int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t 
     if (int rc = frame_bufs(ctx, n_out, batch, fb)) return rc;
     if (pm.mode == 1)   // padded slots of edge tiles and of a short last round: no primitive
         RT_HIP(hipMemsetAsync(fb.id, 0xFF, n_out * sizeof(int32_t), ctx->stream));
-    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, ctx->counting, hit_id_dev, nullptr, &fb, ctx->d_ctr));
+    ctx->queue_used = kQueueSlots;      // a captured or replayed sequence must not depend on earlier calls: always re-zero
+    unsigned int* q = nullptr;
+    if (int rc = next_queue(ctx, &q)) return rc;
+    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
+                             &fb, ctx->d_ctr, q));
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
-        RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, l0, nb, ctx->counting, &fb, ctx->d_ctr));
+        if (int rc = next_queue(ctx, &q)) return rc;
+        RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
+                                ctx->counting, &fb, ctx->d_ctr, q));
         RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &fb, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
     }
     return RT_OK;
@@ -362,7 +398,11 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
     PixelMap pm; uint32_t nw = 0;
     if (int rc = rect_map(cam, rect, pm, nw)) return rc;
     DevCamera dc; to_dev_camera(*cam, dc);
-    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, hit_id_dev, dist_dev, nullptr, ctx->d_ctr));
+    ctx->queue_used = kQueueSlots;
+    unsigned int* q = nullptr;
+    if (int rc = next_queue(ctx, &q)) return rc;
+    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, dist_dev, nullptr,
+                             ctx->d_ctr, q));
     return RT_OK;
 }
 
@@ -395,8 +435,13 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
     if (ctx->sc.n_lights == 0) {
         // no lights: the reference writes an all-black frame without tracing (raytracer.cpp:387-395)
         RT_HIP(hipMemsetAsync(rgb_dev, 0, n_out * 3, ctx->stream));
-        if (hit_id_dev)
-            RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, hit_id_dev, nullptr, nullptr, ctx->d_ctr));
+        if (hit_id_dev) {
+            ctx->queue_used = kQueueSlots;
+            unsigned int* q = nullptr;
+            if (int rc = next_queue(ctx, &q)) return rc;
+            RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
+                                     ctx->d_ctr, q));
+        }
         return RT_OK;
     }
     if (max_scatters > 0) {
@@ -434,7 +479,7 @@ int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int ran
     pm.n_tiles = rt_tile_count(tiling); pm.rank = rank; pm.n_ranks = tiling.n_ranks;
     const uint32_t wpt = static_cast<uint32_t>(tiling.tile / 8) * static_cast<uint32_t>(tiling.tile / 8);
     const uint64_t nw64 = static_cast<uint64_t>(per_rank) * wpt;
-    if (nw64 > 0x0FFFFFFFull) return fail(RT_ERR_LIMIT, "too many tiles for one launch");
+    if (nw64 * 64u * RT_LIGHT_BATCH >= 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "too many tiles for one launch");
     const uint32_t nw = static_cast<uint32_t>(nw64);
     DevCamera dc; to_dev_camera(*cam, dc);
     if (ctx->sc.n_lights == 0 || max_scatters > 0) {

@@ -279,10 +279,12 @@ constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
 DEV uint32_t make_ref(uint32_t first, uint32_t count) { return count ? (count << 28) | first : (first >> 1); }
 DEV bool ref_internal(uint32_t r) { return (r >> 28) == 0u; }
 
-// Per-lane stack: entries 0..RT_STACK_LDS-1 in LDS ([entry][lane]), deeper ones in a private array.
+// Per-lane stack: entries 0..RT_STACK_LDS-1 in LDS ([entry][lane]), deeper ones in a private array that lives
+// outside this struct (a dynamically indexed member would drag every field of the walker into scratch memory).
+struct DeepStack { uint2 e[RT_STACK_DEPTH - RT_STACK_LDS]; };
 struct Stack {
     uint2* lds;                       // this lane's column: lds[e * 64]
-    uint2 deep[RT_STACK_DEPTH - RT_STACK_LDS];
+    uint2* deep;                      // DeepStack::e of the owning kernel
     uint32_t sp;
     DEV void push(uint32_t ref, float t) {
         const uint2 e = make_uint2(ref, __float_as_uint(t));
@@ -302,21 +304,26 @@ struct Stack {
 
 struct Best { double dist; uint32_t slot; int32_t id; };
 
+// One ray's walk through the BVH as a resumable state machine, so that a wave can interleave the walks of its
+// lanes ("while-while") and swap finished rays for fresh ones.
 // MODE 0: closest hit.  MODE 1: shadow verdict for a light at light_dist with the reference's rule
 // "blocked iff the CLOSEST hit lies in (1e-4, light_dist - 1e-4)" (raytracer.cpp:230-235): hits at or
 // beyond light_dist - 1e-4 are irrelevant; once one hit inside the interval is known only hits at
 // <= 1e-4 can still change the verdict, so the search limit collapses to 1e-4; any such hit ends it.
 // vn counts node records fetched (1 for the root, 2 per internal node visited), vp primitive records.
 template <int MODE, bool COUNT>
-DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double light_dist,
-                  Best& best, uint32_t& vn, uint32_t& vp) {
-    BoxRay br; box_ray_init(br, r, sc.radius);
-    best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1;
-    double limit = (MODE == 0) ? __builtin_inf() : (light_dist - 1e-4);
-    float limit_f = f32_up(limit);
-    bool found_mid = false, closed = false;
+struct Walker {
+    RayD r;
+    BoxRay br;
+    Stack st;
+    uint32_t cur;
+    double limit; float limit_f;
+    Best best;                          // MODE 0
+    double light_dist;                  // MODE 1
+    bool found_mid, closed;             // MODE 1
+    uint32_t vn, vp;
 
-    auto test_slot = [&](uint32_t slot) {
+    DEV void test_slot(const DevScene& sc, uint32_t slot) {
         const rt_prim_rec* rec = sc.recs + slot;
         const uint2 tag = *reinterpret_cast<const uint2*>(&rec->kind);
         if (COUNT) ++vp;
@@ -332,46 +339,75 @@ DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double li
             if (h.dist <= 1e-4) { closed = true; return; }
             if (h.dist < light_dist - 1e-4 && !found_mid) { found_mid = true; limit = 1e-4; limit_f = f32_up(limit); }
         }
-    };
+    }
 
-    if (sc.n_nodes) {
-        const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
-        Stack st; st.lds = lds_stack; st.sp = 0;
-        uint32_t cur = REF_NONE;
-        {
+    // Root box test; afterwards cur is the first node reference or REF_NONE.
+    DEV void start(const DevScene& sc, const RayD& ray, uint2* lds_stack, uint2* deep_stack, double ldist) {
+        r = ray;
+        box_ray_init(br, r, sc.radius);
+        st.lds = lds_stack; st.deep = deep_stack; st.sp = 0;
+        best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1;
+        light_dist = ldist; found_mid = false; closed = false;
+        limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
+        limit_f = f32_up(limit);
+        cur = REF_NONE;
+        if (sc.n_nodes) {
+            const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
             const float4 lo = nodes[0], hi = nodes[1];
             if (COUNT) vn += 1;
             if (box_entry(lo, hi, br, limit_f) != __builtin_inff()) cur = make_ref(__float_as_uint(lo.w), __float_as_uint(hi.w));
         }
-        while (cur != REF_NONE) {
-            // inner nodes: the wave stays here until every lane holds a leaf or has run out of nodes
-            while (ref_internal(cur)) {
-                const float4* pair = nodes + 4u * static_cast<size_t>(cur);
-                const float4 llo = pair[0], lhi = pair[1], rlo = pair[2], rhi = pair[3];
-                if (COUNT) vn += 2;
-                const float tl = box_entry(llo, lhi, br, limit_f), tr = box_entry(rlo, rhi, br, limit_f);
-                const bool hl = tl != __builtin_inff(), hr = tr != __builtin_inff();
-                const uint32_t lref = make_ref(__float_as_uint(llo.w), __float_as_uint(lhi.w));
-                const uint32_t rref = make_ref(__float_as_uint(rlo.w), __float_as_uint(rhi.w));
-                if (hl && hr) {
-                    if (tr < tl) { st.push(lref, tl); cur = rref; }
-                    else         { st.push(rref, tr); cur = lref; }
-                } else if (hl) cur = lref;
-                else if (hr)   cur = rref;
-                else           cur = st.pop(limit_f);
-            }
-            if (cur == REF_NONE) break;
-            const uint32_t first = cur & 0x0FFFFFFFu, count = cur >> 28;
-            for (uint32_t s = 0; s < count && !(MODE == 1 && closed); ++s) test_slot(first + s);
-            if (MODE == 1 && closed) break;
-            cur = st.pop(limit_f);
-        }
     }
-    // unbounded primitives (a zero or non-finite scale): tested against every ray
-    if (!closed)
-        for (uint32_t s = 0; s < sc.n_loose && !closed; ++s) test_slot(sc.n_slots + s);
-    if (MODE == 0) return best.id >= 0;
-    return found_mid && !closed;
+    DEV bool at_internal() const { return ref_internal(cur); }
+    DEV bool done() const { return cur == REF_NONE; }
+
+    // One internal node: fetch both children (64 contiguous bytes), test, descend into the nearer, postpone the other.
+    DEV void step_internal(const DevScene& sc) {
+        const float4* pair = reinterpret_cast<const float4*>(sc.nodes) + 4u * static_cast<size_t>(cur);
+        const float4 llo = pair[0], lhi = pair[1], rlo = pair[2], rhi = pair[3];
+        if (COUNT) vn += 2;
+        const float tl = box_entry(llo, lhi, br, limit_f), tr = box_entry(rlo, rhi, br, limit_f);
+        const bool hl = tl != __builtin_inff(), hr = tr != __builtin_inff();
+        const uint32_t lref = make_ref(__float_as_uint(llo.w), __float_as_uint(lhi.w));
+        const uint32_t rref = make_ref(__float_as_uint(rlo.w), __float_as_uint(rhi.w));
+        if (hl && hr) {
+            if (tr < tl) { st.push(lref, tl); cur = rref; }
+            else         { st.push(rref, tr); cur = lref; }
+        } else if (hl) cur = lref;
+        else if (hr)   cur = rref;
+        else           cur = st.pop(limit_f);
+    }
+
+    // cur is a leaf: test its primitives, then take the next postponed node.
+    DEV void step_leaf(const DevScene& sc) {
+        const uint32_t first = cur & 0x0FFFFFFFu, count = cur >> 28;
+        for (uint32_t s = 0; s < count && !(MODE == 1 && closed); ++s) test_slot(sc, first + s);
+        cur = (MODE == 1 && closed) ? REF_NONE : st.pop(limit_f);
+    }
+
+    // Unbounded primitives (a zero or non-finite scale) are tested against every ray, after the walk.
+    DEV void finish(const DevScene& sc) {
+        for (uint32_t s = 0; s < sc.n_loose && !closed; ++s) test_slot(sc, sc.n_slots + s);
+    }
+    DEV bool hit() const { return best.id >= 0; }                  // MODE 0
+    DEV bool blocked() const { return found_mid && !closed; }      // MODE 1
+};
+
+// A whole walk in one go (arbitrary-ray and bounce kernels).
+template <int MODE, bool COUNT>
+DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double light_dist,
+                  Best& best, uint32_t& vn, uint32_t& vp) {
+    Walker<MODE, COUNT> w; w.vn = 0; w.vp = 0;
+    DeepStack deep;
+    w.start(sc, r, lds_stack, deep.e, light_dist);
+    while (!w.done()) {
+        // inner nodes: the wave stays here until every lane holds a leaf or has run out of nodes
+        while (w.at_internal()) w.step_internal(sc);
+        if (!w.done()) w.step_leaf(sc);
+    }
+    w.finish(sc);
+    best = w.best; vn += w.vn; vp += w.vp;
+    return MODE == 0 ? w.hit() : w.blocked();
 }
 
 // ---- shading -----------------------------------------------------------------------------------
@@ -390,28 +426,31 @@ DEV uint32_t round_u8(double c) {
 
 struct ShadeCounters { uint32_t shadow_rays, vn, vp; };
 
-// One light's term of RayTracer::shade (raytracer.cpp:210-260) at a surface point with unit normal n (already
-// re-normalised) seen from view_o: shadow ray, then attenuation * (diffuse + specular); 0 when blocked.
-template <bool COUNT>
-DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
-                      double nx, double ny, double nz, double view_ox, double view_oy, double view_oz,
-                      uint2* lds_stack, ShadeCounters& ctr) {
+// Shadow ray of RayTracer::shade (raytracer.cpp:210-228) from a surface point with unit normal n towards light L:
+// origin nudged 1e-4 along the normal on the light's side, unit direction.  Returns the light distance.
+DEV double shadow_ray(const rt_light& L, double px, double py, double pz, double nx, double ny, double nz, RayD& sr) {
     const double lx = L.pos[0] - px, ly = L.pos[1] - py, lz = L.pos[2] - pz;
     const double len2 = lx*lx + ly*ly + lz*lz;
     const double dist2 = (1e-12 < len2) ? len2 : 1e-12;
     double dx, dy, dz; normalize3(lx, ly, lz, dx, dy, dz);
-    const double light_dist = dsqrt(dist2);
     const double eps = 1e-4;
     const double ndl = nx*dx + ny*dy + nz*dz;
     const double s = (ndl >= 0.0) ? 1.0 : -1.0;
-    RayD sr;
     sr.ox = px + s * nx * eps; sr.oy = py + s * ny * eps; sr.oz = pz + s * nz * eps;
     sr.dx = dx; sr.dy = dy; sr.dz = dz;
     sr.dlen = dsqrt(dx*dx + dy*dy + dz*dz);
-    Best b;
-    ++ctr.shadow_rays;
-    if (traverse<1, COUNT>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
+    return dsqrt(dist2);
+}
 
+// An unblocked light's term, attenuation * (diffuse + specular) (raytracer.cpp:242-259); (dx,dy,dz) is the unit
+// direction to the light exactly as shadow_ray produced it.
+DEV double light_value(const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
+                       double nx, double ny, double nz, double dx, double dy, double dz,
+                       double view_ox, double view_oy, double view_oz) {
+    const double lx = L.pos[0] - px, ly = L.pos[1] - py, lz = L.pos[2] - pz;
+    const double len2 = lx*lx + ly*ly + lz*lz;
+    const double dist2 = (1e-12 < len2) ? len2 : 1e-12;
+    const double ndl = nx*dx + ny*dy + nz*dz;
     const double metallic = clampd(m.metallic, 0.0, 1.0);
     const double roughness = clampd(m.roughness, 0.001, 1.0);
     const double e_raw = (2.0 / (roughness * roughness)) - 2.0;
@@ -425,6 +464,19 @@ DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m
     const double specular = (0.5 * 1.25) * pow(n_dot_h, phong_exp);
     const double attenuation = L.intensity / dist2;
     return attenuation * (diffuse + specular);
+}
+
+// One light's term of RayTracer::shade (raytracer.cpp:210-260) in one go; 0 when the light is blocked.
+template <bool COUNT>
+DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
+                      double nx, double ny, double nz, double view_ox, double view_oy, double view_oz,
+                      uint2* lds_stack, ShadeCounters& ctr) {
+    RayD sr;
+    const double light_dist = shadow_ray(L, px, py, pz, nx, ny, nz, sr);
+    Best b;
+    ++ctr.shadow_rays;
+    if (traverse<1, COUNT>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
+    return light_value(L, m, px, py, pz, nx, ny, nz, sr.dx, sr.dy, sr.dz, view_ox, view_oy, view_oz);
 }
 
 // Ambient, clamp, albedo, 8-bit quantisation (raytracer.cpp:262-278); packed r | g << 8 | b << 16.
@@ -487,8 +539,7 @@ struct Pixel { int x, y; uint32_t out; bool valid; };
 
 // Wave `w` of the pixel map owns one 8x8 tile, lanes in Z-order.  Rectangle mode: waves run in Z-order inside
 // 128x128-pixel super tiles.  Tile mode: a rank's tiles one after the other, 8x8 blocks row-major inside a tile.
-DEV Pixel map_pixel(const PixelMap& pm, uint32_t w) {
-    const uint32_t lane = threadIdx.x & 63u;
+DEV Pixel map_pixel(const PixelMap& pm, uint32_t w, uint32_t lane) {
     const int lx = static_cast<int>(compact1by1(lane)), ly = static_cast<int>(compact1by1(lane >> 1));
     Pixel p; p.valid = false; p.x = 0; p.y = 0; p.out = 0;
     if (pm.mode == 0) {
@@ -537,64 +588,125 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 
 // ---- kernels -------------------------------------------------------------------------------------
 
-// Primary rays over a pixel map: closest hit.  ids / dist (optional) are the caller's outputs; with a FrameBufs
-// the surface record of every hit (point, re-normalised normal, id) is kept for the shadow pass.
-template <bool COUNT, bool RECORD>
-__global__ void __launch_bounds__(64) k_primary(DevScene sc, DevCamera cam, PixelMap pm, int32_t* __restrict__ ids,
-                                                double* __restrict__ dist, FrameBufs fb, rt_counters* ctr) {
+// Persistent ray kernel.  Every wave loops: lanes whose ray has finished write their result, then all free lanes
+// take the next rays of the wave's current chunk (chunks of RT_CHUNK consecutive rays are handed out by one atomic
+// counter), then the wave advances all its walks by one while-while round.  Finished lanes are only swapped once
+// RT_REFILL_MIN of them have piled up, so that the result / set-up code also runs on a well-filled wave.
+// MODE 0 - primary rays: ray i = lane (i % 64) of tile (i / 64) of the pixel map; writes ids / dist (optional) and,
+//          with RECORD, the surface record (point, re-normalised normal, id) the shadow pass starts from.
+// MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
+//          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
+template <int MODE, bool COUNT, bool RECORD>
+__global__ void __launch_bounds__(64) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
+                                             uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
+                                             FrameBufs fb, rt_counters* ctr, unsigned int* queue) {
     __shared__ uint2 stack[RT_STACK_LDS * 64];
-    const uint32_t w = xcd_contiguous(blockIdx.x, gridDim.x);
-    const Pixel p = map_pixel(pm, w);
-    bool hit = false;
-    uint32_t vn = 0, vp = 0;
-    if (p.valid) {
-        RayD r; primary_ray(cam, static_cast<double>(p.x) + 0.5, static_cast<double>(p.y) + 0.5, r);
-        Best b;
-        hit = traverse<0, COUNT>(sc, r, stack + (threadIdx.x & 63u), 0.0, b, vn, vp);
-        if (ids) ids[p.out] = b.id;
-        if (dist) dist[p.out] = b.dist;
-        if (RECORD) {
-            fb.id[p.out] = b.id;
-            if (hit) {
-                HitD h;
-                const rt_prim_rec* rec = sc.recs + b.slot;
-                hit_record<true>(rec, rec->kind, r, h);
-                double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);     // shade() re-normalises (raytracer.cpp:182)
-                fb.px[p.out] = h.px; fb.py[p.out] = h.py; fb.pz[p.out] = h.pz;
-                fb.nx[p.out] = nx;   fb.ny[p.out] = ny;   fb.nz[p.out] = nz;
-            }
-        }
-    }
-    const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
-    add_counter(ctr, shard, F_PRIMARY, p.valid ? 1 : 0);
-    add_counter(ctr, shard, F_HITS, hit ? 1 : 0);
-    if (COUNT) { add_counter(ctr, shard, F_VN_P, vn); add_counter(ctr, shard, F_VP_P, vp); }
-}
+    const uint32_t lane = threadIdx.x & 63u;
+    uint2* my_stack = stack + lane;
+    enum { IDLE = 0, TRAV = 1, DONE = 2 };
+    uint32_t state = IDLE, out = 0, ridx = 0;
+    Walker<MODE, COUNT> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
+    DeepStack deep;
+    uint32_t n_cast = 0, n_hit = 0;
+    uint32_t q_next = 0, q_end = 0;          // wave-uniform: the unread part of the current chunk
+    bool q_empty = false;
 
-// Shadow pass: wave (light, tile).  All lanes of a wave aim at the same light from neighbouring surface
-// points.  Writes this light's term of the lighting sum for every hit pixel of the tile.
-template <bool COUNT>
-__global__ void __launch_bounds__(64) k_shadow(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_waves, uint32_t light0,
-                                               FrameBufs fb, rt_counters* ctr) {
-    __shared__ uint2 stack[RT_STACK_LDS * 64];
-    const uint32_t g = xcd_contiguous(blockIdx.x, gridDim.x);
-    const uint32_t lj = g / n_waves, w = g % n_waves;
-    const Pixel p = map_pixel(pm, w);
-    ShadeCounters sctr = { 0, 0, 0 };
-    if (p.valid) {
-        const int32_t id = fb.id[p.out];
-        if (id >= 0) {
-            const rt_light L = sc.lights[light0 + lj];
-            const rt_mat_rec m = sc.mats[id];
-            const double c = light_term<COUNT>(sc, L, m, fb.px[p.out], fb.py[p.out], fb.pz[p.out],
-                                               fb.nx[p.out], fb.ny[p.out], fb.nz[p.out],
-                                               cam.pos[0], cam.pos[1], cam.pos[2], stack + (threadIdx.x & 63u), sctr);
-            fb.contrib[static_cast<size_t>(lj) * fb.n + p.out] = c;
+    for (;;) {
+        const int n_trav = __popcll(__ballot(state == TRAV));
+        const int n_done = __popcll(__ballot(state == DONE));
+        const bool swap = n_trav == 0 || (q_empty ? n_done >= RT_REFILL_MIN : 64 - n_trav >= RT_REFILL_MIN);
+        if (swap) {
+            // ---- results of finished rays -----------------------------------------------------------------
+            if (state == DONE) {
+                if (sc.n_loose) w.finish(sc);
+                if (MODE == 0) {
+                    const bool hit = w.hit();
+                    n_hit += hit ? 1u : 0u;
+                    if (ids) ids[out] = w.best.id;
+                    if (dist) dist[out] = w.best.dist;
+                    if (RECORD) {
+                        fb.id[out] = w.best.id;
+                        if (hit) {
+                            HitD h;
+                            const rt_prim_rec* rec = sc.recs + w.best.slot;
+                            hit_record<true>(rec, rec->kind, w.r, h);
+                            double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
+                            fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
+                            fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
+                        }
+                    }
+                } else {
+                    double c = 0.0;
+                    const uint32_t lj = (ridx >> 6) / n_tiles;
+                    if (!w.blocked()) {
+                        const rt_light L = sc.lights[light0 + lj];
+                        const rt_mat_rec m = sc.mats[fb.id[out]];
+                        c = light_value(L, m, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out],
+                                        w.r.dx, w.r.dy, w.r.dz, cam.pos[0], cam.pos[1], cam.pos[2]);
+                    }
+                    fb.contrib[static_cast<size_t>(lj) * fb.n + out] = c;
+                }
+                state = IDLE;
+            }
+            // ---- fresh rays for the free lanes ---------------------------------------------------------------
+            while (!q_empty) {
+                const unsigned long long idle = __ballot(state == IDLE);
+                if (!idle) break;
+                if (q_next == q_end) {
+                    unsigned int c = 0;
+                    if (lane == 0) c = atomicAdd(queue, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    const unsigned long long first = static_cast<unsigned long long>(c) * RT_CHUNK;
+                    if (first >= n_rays) { q_empty = true; break; }
+                    q_next = static_cast<uint32_t>(first);
+                    q_end = (n_rays - q_next < RT_CHUNK) ? n_rays : q_next + RT_CHUNK;
+                }
+                const uint32_t avail = q_end - q_next, n_idle = static_cast<uint32_t>(__popcll(idle));
+                const uint32_t take = n_idle < avail ? n_idle : avail;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+                if (state == IDLE && rank < take) {
+                    ridx = q_next + rank;
+                    const uint32_t g = ridx >> 6;
+                    const Pixel p = map_pixel(pm, MODE == 0 ? g : g % n_tiles, ridx & 63u);
+                    if (p.valid) {
+                        out = p.out;
+                        if (MODE == 0) {
+                            RayD r; primary_ray(cam, static_cast<double>(p.x) + 0.5, static_cast<double>(p.y) + 0.5, r);
+                            w.start(sc, r, my_stack, deep.e, 0.0);
+                            ++n_cast;
+                            state = w.done() ? DONE : TRAV;
+                        } else if (fb.id[out] >= 0) {
+                            const rt_light L = sc.lights[light0 + g / n_tiles];
+                            RayD r;
+                            const double ld = shadow_ray(L, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out], r);
+                            w.start(sc, r, my_stack, deep.e, ld);
+                            ++n_cast;
+                            state = w.done() ? DONE : TRAV;
+                        }
+                    }
+                }
+                q_next += take;
+            }
+            if (__ballot(state != IDLE) == 0) { if (q_empty) break; else continue; }
+            if (__ballot(state == TRAV) == 0) continue;          // only finished rays on board: write them out first
+        }
+        // ---- one while-while round for the rays in flight ----------------------------------------------------------
+        if (state == TRAV) {
+            while (w.at_internal()) w.step_internal(sc);
+            if (!w.done()) w.step_leaf(sc);
+            if (w.done()) state = DONE;
         }
     }
     const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
-    add_counter(ctr, shard, F_SHADOW, sctr.shadow_rays);
-    if (COUNT) { add_counter(ctr, shard, F_VN_S, sctr.vn); add_counter(ctr, shard, F_VP_S, sctr.vp); }
+    if (MODE == 0) {
+        add_counter(ctr, shard, F_PRIMARY, n_cast);
+        add_counter(ctr, shard, F_HITS, n_hit);
+        if (COUNT) { add_counter(ctr, shard, F_VN_P, w.vn); add_counter(ctr, shard, F_VP_P, w.vp); }
+    } else {
+        add_counter(ctr, shard, F_SHADOW, n_cast);
+        if (COUNT) { add_counter(ctr, shard, F_VN_S, w.vn); add_counter(ctr, shard, F_VP_S, w.vp); }
+    }
 }
 
 // Sum the light terms in light order (the reference's accumulation order), then ambient, albedo, gamma.
@@ -666,7 +778,7 @@ __global__ void __launch_bounds__(64) k_render_bounce(DevScene sc, DevCamera cam
     __shared__ uint2 stack[RT_STACK_LDS * 64];
     uint2* my_stack = stack + (threadIdx.x & 63u);
     const uint32_t w = xcd_contiguous(blockIdx.x, gridDim.x);
-    const Pixel p = map_pixel(pm, w);
+    const Pixel p = map_pixel(pm, w, threadIdx.x & 63u);
     ShadeCounters sctr = { 0, 0, 0 };
     uint32_t vn = 0, vp = 0, bounce_rays = 0;
     bool primary_hit = false;
@@ -756,25 +868,26 @@ __global__ void __launch_bounds__(256) k_assemble_tiles(int width, int height, i
 // ---- host-callable launchers (called from rt_capi.cpp) ---------------------------------------------
 
 extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
-                                        uint32_t n_waves, int counting, int32_t* ids, double* dist, const FrameBufs* fb,
-                                        rt_counters* ctr) {
+                                        uint32_t n_tiles, uint32_t n_waves, int counting, int32_t* ids, double* dist,
+                                        const FrameBufs* fb, rt_counters* ctr, unsigned int* queue) {
     const FrameBufs none{};
+    const uint32_t n_rays = n_tiles * 64u;
     if (fb) {
-        if (counting) hipLaunchKernelGGL((k_primary<true, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, ids, dist, *fb, ctr);
-        else          hipLaunchKernelGGL((k_primary<false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, ids, dist, *fb, ctr);
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue);
+        else          hipLaunchKernelGGL((k_rays<0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue);
     } else {
-        if (counting) hipLaunchKernelGGL((k_primary<true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, ids, dist, none, ctr);
-        else          hipLaunchKernelGGL((k_primary<false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, ids, dist, none, ctr);
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue);
+        else          hipLaunchKernelGGL((k_rays<0, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue);
     }
     return hipGetLastError();
 }
 
 extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
-                                       uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb,
-                                       rt_counters* ctr) {
-    const uint32_t grid = n_waves * n_batch;
-    if (counting) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(64), 0, st, *sc, *cam, *pm, n_waves, light0, *fb, ctr);
-    else          hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(64), 0, st, *sc, *cam, *pm, n_waves, light0, *fb, ctr);
+                                       uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
+                                       const FrameBufs* fb, rt_counters* ctr, unsigned int* queue) {
+    const uint32_t n_rays = n_tiles * n_batch * 64u;
+    if (counting) hipLaunchKernelGGL((k_rays<1, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue);
+    else          hipLaunchKernelGGL((k_rays<1, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue);
     return hipGetLastError();
 }
 
