@@ -50,6 +50,7 @@ struct rt_ctx {
     unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
     uint32_t queue_used = kQueueSlots;     // slots consumed since the last zeroing
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
+    int refill_min = RT_REFILL_MIN;
     // grow-only scratch of the *_host conveniences
     void* scratch[4] = { nullptr, nullptr, nullptr, nullptr };    // 0..2 host conveniences, 3 frame working set
     size_t scratch_bytes[4] = { 0, 0, 0, 0 };
@@ -241,6 +242,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
             int per_cu = 16;                                   // 4 waves per SIMD at <= 128 VGPRs
             if (const char* env = std::getenv("RT_WAVES_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 32) per_cu = v; }
             c->max_waves = static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu;
+            if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_min = v; }
         }
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 256);
@@ -379,12 +381,12 @@ int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t 
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, &q)) return rc;
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
-                             &fb, ctx->d_ctr, q));
+                             &fb, ctx->d_ctr, q, ctx->refill_min));
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
         if (int rc = next_queue(ctx, &q)) return rc;
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
-                                ctx->counting, &fb, ctx->d_ctr, q));
+                                ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
         RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &fb, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
     }
     return RT_OK;
@@ -402,7 +404,7 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, &q)) return rc;
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, dist_dev, nullptr,
-                             ctx->d_ctr, q));
+                             ctx->d_ctr, q, ctx->refill_min));
     return RT_OK;
 }
 
@@ -440,7 +442,7 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
             unsigned int* q = nullptr;
             if (int rc = next_queue(ctx, &q)) return rc;
             RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
-                                     ctx->d_ctr, q));
+                                     ctx->d_ctr, q, ctx->refill_min));
         }
         return RT_OK;
     }

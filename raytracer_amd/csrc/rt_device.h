@@ -9,8 +9,11 @@
 #define RT_CTR_SHARDS 64           // counter replicas, one cache line each, summed on read
 #define RT_CTR_STRIDE 16           // 64-bit words between replicas (128 bytes)
 #define RT_LIGHT_BATCH 8           // lights per shadow launch (bounds the contribution planes)
+#ifndef RT_RAYS_MIN_WAVES
+#define RT_RAYS_MIN_WAVES 4        // waves per SIMD the persistent kernel is compiled for (caps VGPRs at 128)
+#endif
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
-#define RT_REFILL_MIN 16           // finished lanes that must pile up before a wave swaps rays
+#define RT_REFILL_MIN 40           // finished lanes that must pile up before a wave swaps rays (default)
 
 struct DevScene {
     const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
@@ -55,10 +58,10 @@ extern "C" {
 // 32-bit counter per launch.
 hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                              uint32_t n_tiles, uint32_t n_waves, int counting, int32_t* ids, double* dist,
-                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue);
+                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
 hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                             uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
-                            const FrameBufs* fb, rt_counters* ctr, unsigned int* queue);
+                            const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
 hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, uint32_t n_batch, int first, int last, uint8_t* rgb);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, rt_counters* ctr);

@@ -282,20 +282,23 @@ DEV bool ref_internal(uint32_t r) { return (r >> 28) == 0u; }
 // Per-lane stack: entries 0..RT_STACK_LDS-1 in LDS ([entry][lane]), deeper ones in a private array that lives
 // outside this struct (a dynamically indexed member would drag every field of the walker into scratch memory).
 struct DeepStack { uint2 e[RT_STACK_DEPTH - RT_STACK_LDS]; };
+// The LDS part is one file-scope array, indexed directly, so that the compiler emits ds_read / ds_write (a pointer
+// kept in a struct degrades to flat addressing).  Every ray kernel runs one wave per workgroup.
+__shared__ uint2 g_lds_stack[RT_STACK_LDS * 64];
 struct Stack {
-    uint2* lds;                       // this lane's column: lds[e * 64]
     uint2* deep;                      // DeepStack::e of the owning kernel
+    uint32_t lane;                    // this lane's column of g_lds_stack
     uint32_t sp;
     DEV void push(uint32_t ref, float t) {
         const uint2 e = make_uint2(ref, __float_as_uint(t));
-        if (sp < RT_STACK_LDS) lds[sp * 64u] = e; else deep[sp - RT_STACK_LDS] = e;
+        if (sp < RT_STACK_LDS) g_lds_stack[sp * 64u + lane] = e; else deep[sp - RT_STACK_LDS] = e;
         ++sp;
     }
     // next entry that still starts before `limit`, or REF_NONE
     DEV uint32_t pop(float limit) {
         while (sp) {
             --sp;
-            const uint2 e = (sp < RT_STACK_LDS) ? lds[sp * 64u] : deep[sp - RT_STACK_LDS];
+            const uint2 e = (sp < RT_STACK_LDS) ? g_lds_stack[sp * 64u + lane] : deep[sp - RT_STACK_LDS];
             if (__uint_as_float(e.y) <= limit) return e.x;
         }
         return REF_NONE;
@@ -345,7 +348,8 @@ struct Walker {
     DEV void start(const DevScene& sc, const RayD& ray, uint2* lds_stack, uint2* deep_stack, double ldist) {
         r = ray;
         box_ray_init(br, r, sc.radius);
-        st.lds = lds_stack; st.deep = deep_stack; st.sp = 0;
+        (void)lds_stack;
+        st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1;
         light_dist = ldist; found_mid = false; closed = false;
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
@@ -597,12 +601,11 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
 template <int MODE, bool COUNT, bool RECORD>
-__global__ void __launch_bounds__(64) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
+__global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
-                                             FrameBufs fb, rt_counters* ctr, unsigned int* queue) {
-    __shared__ uint2 stack[RT_STACK_LDS * 64];
+                                             FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint2* my_stack = stack + lane;
+    uint2* my_stack = nullptr;
     enum { IDLE = 0, TRAV = 1, DONE = 2 };
     uint32_t state = IDLE, out = 0, ridx = 0;
     Walker<MODE, COUNT> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
@@ -614,7 +617,7 @@ __global__ void __launch_bounds__(64) k_rays(DevScene sc, DevCamera cam, PixelMa
     for (;;) {
         const int n_trav = __popcll(__ballot(state == TRAV));
         const int n_done = __popcll(__ballot(state == DONE));
-        const bool swap = n_trav == 0 || (q_empty ? n_done >= RT_REFILL_MIN : 64 - n_trav >= RT_REFILL_MIN);
+        const bool swap = n_trav == 0 || (q_empty ? n_done >= refill_min : 64 - n_trav >= refill_min);
         if (swap) {
             // ---- results of finished rays -----------------------------------------------------------------
             if (state == DONE) {
@@ -732,8 +735,7 @@ template <bool COUNT, bool SHADE>
 __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __restrict__ rays, uint64_t n,
                                                    int32_t* __restrict__ ids, double* __restrict__ dist,
                                                    uint8_t* __restrict__ rgb, rt_counters* ctr) {
-    __shared__ uint2 stack[RT_STACK_LDS * 64];
-    uint2* my_stack = stack + (threadIdx.x & 63u);
+    uint2* my_stack = nullptr;
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
     bool hit = false;
     uint32_t vn = 0, vp = 0;
@@ -775,8 +777,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(64) k_render_bounce(DevScene sc, DevCamera cam, PixelMap pm, int max_scatters,
                                                       double min_scatter_intensity, uint8_t* __restrict__ rgb,
                                                       int32_t* __restrict__ ids, rt_counters* ctr) {
-    __shared__ uint2 stack[RT_STACK_LDS * 64];
-    uint2* my_stack = stack + (threadIdx.x & 63u);
+    uint2* my_stack = nullptr;
     const uint32_t w = xcd_contiguous(blockIdx.x, gridDim.x);
     const Pixel p = map_pixel(pm, w, threadIdx.x & 63u);
     ShadeCounters sctr = { 0, 0, 0 };
@@ -869,25 +870,25 @@ __global__ void __launch_bounds__(256) k_assemble_tiles(int width, int height, i
 
 extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                                         uint32_t n_tiles, uint32_t n_waves, int counting, int32_t* ids, double* dist,
-                                        const FrameBufs* fb, rt_counters* ctr, unsigned int* queue) {
+                                        const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const FrameBufs none{};
     const uint32_t n_rays = n_tiles * 64u;
     if (fb) {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue);
-        else          hipLaunchKernelGGL((k_rays<0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue);
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
     } else {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue);
-        else          hipLaunchKernelGGL((k_rays<0, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue);
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<0, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
     }
     return hipGetLastError();
 }
 
 extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                                        uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
-                                       const FrameBufs* fb, rt_counters* ctr, unsigned int* queue) {
+                                       const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t n_rays = n_tiles * n_batch * 64u;
-    if (counting) hipLaunchKernelGGL((k_rays<1, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue);
-    else          hipLaunchKernelGGL((k_rays<1, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue);
+    if (counting) hipLaunchKernelGGL((k_rays<1, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+    else          hipLaunchKernelGGL((k_rays<1, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
     return hipGetLastError();
 }
 
