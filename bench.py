@@ -30,13 +30,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 NODE_BYTES, PRIM_BYTES = 32, 64
 
 
-def algorithmic_bytes(c):
-    """Per-frame algorithmic traffic: 32 B per BVH node fetched, 64 B per primitive record fetched, 8 B written
-    per primary ray ({hit id, t}), 8 B read + 1 B written per shadow ray."""
-    return (NODE_BYTES * (c["nodes_primary"] + c["nodes_shadow"]) + PRIM_BYTES * (c["prims_primary"] + c["prims_shadow"])
-            + 8 * c["primary_rays"] + 9 * c["shadow_rays"])
-
-
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -163,35 +156,40 @@ def main():
     if dist is not None:
         dist.all_reduce(tot)
     total = dict(zip(keys, (int(v) for v in tot.tolist())))
-    my_bytes = algorithmic_bytes(c)
     rays_per_frame = total["primary_rays"] + total["shadow_rays"] + total["bounce_rays"]
+    # algorithmic bytes of this rank's launches, per kernel: 32 B per node record fetched, 64 B per primitive record
+    # fetched, 8 B written per primary ray, 8 B read + 1 B written per shadow ray
+    bytes_primary = NODE_BYTES * c["nodes_primary"] + PRIM_BYTES * c["prims_primary"] + 8 * c["primary_rays"]
+    bytes_shadow = NODE_BYTES * c["nodes_shadow"] + PRIM_BYTES * c["prims_shadow"] + 9 * c["shadow_rays"]
 
     for _ in range(args.warmup):
         step()
     fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ctx.set_timing(True)          # HIP events around every launch, on the stream the kernels run on
+    ctx.timing()
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)          # brackets the render launch only (the dominant kernel) on its own stream
-        if world == 1:
-            step()
-            b.record(stream)
-        else:
-            ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
-            b.record(stream)
-            dist.gather(local, glist, dst=0)
-            if rank == 0:
-                ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+    for _ in range(args.steps):
+        step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    tm = ctx.timing()
+    ctx.set_timing(False)
+    if args.max_scatters > 0:
+        kname, k_ms, k_bytes = "k_render_bounce<false>", tm["bounce_ms"] / max(tm["bounce_launches"], 1), bytes_primary + bytes_shadow
+    else:
+        # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights
+        kname, k_ms, k_bytes = "k_rays<1,false,false> (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
+            bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
+    stage_ms = {k: tm[k] / args.steps for k in ("primary_ms", "shadow_ms", "resolve_ms", "bounce_ms")}
+    t = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max = (float(v) for v in t.tolist())
+    elapsed, k_ms_max = (float(v) for v in t.tolist())
 
     if rank == 0:
-        achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        frame_bytes = bytes_primary + bytes_shadow
+        device_ms = sum(stage_ms.values())
         out = {
             "metric": "Mrays/sec (primary+shadow) at %dx%d" % (W, H),
             "value": rays_per_frame * args.steps / elapsed / 1e6,
@@ -201,7 +199,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64 leaf tests + f32 box tests",
+            "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "1M-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
@@ -211,13 +209,16 @@ def main():
                 "partition": "image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
                 "shadow_rays": total["shadow_rays"], "scene_build_s": round(build_s, 3),
+                "arithmetic": "FP32 padded-box traversal, FP64 leaf tests and shading",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "k_render<false,%s>" % ("true" if args.max_scatters > 0 else "false"),
-                "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
-                "algorithmic_bytes_per_launch": my_bytes,
+                "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,
+                "algorithmic_bytes_per_launch": k_bytes,
+                "stage_ms_per_frame": stage_ms,
+                "frame_algorithmic_bytes": frame_bytes,
+                "frame_achieved_GBps": frame_bytes / (device_ms * 1e-3) / 1e9 if device_ms > 0 else None,
                 "nodes_per_primary_ray": c["nodes_primary"] / max(c["primary_rays"], 1),
                 "prims_per_primary_ray": c["prims_primary"] / max(c["primary_rays"], 1),
                 "nodes_per_shadow_ray": c["nodes_shadow"] / max(c["shadow_rays"], 1),

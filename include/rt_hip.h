@@ -94,6 +94,12 @@ typedef struct rt_counters {
     uint64_t nodes_shadow, prims_shadow;
 } rt_counters;
 
+/* Device time of the frame pipeline's launches, measured with HIP events on the context's stream. */
+typedef struct rt_timing {
+    double   primary_ms, shadow_ms, resolve_ms, bounce_ms;        /* summed over the launches below */
+    uint32_t primary_launches, shadow_launches, resolve_launches, bounce_launches;
+} rt_timing;
+
 typedef struct rt_scene rt_scene;   /* host side: descriptions + flattened records + BVH */
 typedef struct rt_ctx rt_ctx;       /* one GPU: stream, device copy of a scene, scratch outputs */
 
@@ -148,11 +154,26 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
 int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit_id_dev, double* dist_dev);
 /* one_pass_intersection + RayTracer::shade (raytracer.h:34) for n arbitrary rays: linear 8-bit colour, no gamma. */
 int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb_dev);
+/* one_pass_intersection returning the reference's whole Hit (utils.h:68-112) per ray, 16 doubles each:
+ * [0] 1 = hit / 0 = miss, [1] primitive id (-1 on a miss), [2] distance along the ray, [3..5] intersection point,
+ * [6..8] surface normal, [9..11] reflected direction, [12..13] surface u, v (mesh.cpp:262-278, 497-512, 669-679, 918;
+ * triangles: barycentric edge coordinates), [14..15] zero. */
+int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double* records16_dev);
+/* RayTracer::shade (raytracer.h:34, raytracer.cpp:159-279) for caller-supplied hits: 8 doubles each ([0..2] point,
+ * [3..5] normal, [6] primitive id, [7] unused; id outside the scene = miss = black) and the origin of the ray that
+ * produced each hit (3 doubles).  Linear 8-bit colour. */
+int rt_shade_hits(rt_ctx* ctx, const double* hits8_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev);
 /* RayTracer::render_unaccelerated_ppm's pixel loop with samples_per_pixel = 1 (raytracer.cpp:401-438):
  * trace, shade with hard shadows, up to max_scatters mirror bounces (<= 8), gamma.  rgb_dev is
  * rect.w * rect.h * 3 bytes; hit_id_dev (may be NULL) receives the primary hit ids. */
 int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
                    uint8_t* rgb_dev, int32_t* hit_id_dev);
+/* The same loop with samples_per_pixel > 1 (raytracer.cpp:403-436): sample 0 through the pixel centre, later samples
+ * offset by up to half a pixel; per-sample linear 8-bit colours are averaged, rounded, then gamma encoded.  The
+ * reference seeds its offsets from std::random_device, so frames differ run to run; here they are a pure function
+ * of (seed, sample, pixel). */
+int rt_render_samples(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int samples_per_pixel, uint32_t seed, int max_scatters,
+                      double min_scatter_intensity, uint8_t* rgb_dev);
 /* The same pixel pipeline over this rank's share of a tiled frame; rgb_dev holds
  * rt_tiles_per_rank(tiling) * tile * tile * 3 bytes. */
 int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int rank, int max_scatters,
@@ -165,6 +186,10 @@ int32_t rt_tile_count(rt_tiling tiling);
 /* Ray and (for the counting variants) node / primitive fetch counters accumulated since the last reset. */
 int rt_counters_reset(rt_ctx* ctx);
 int rt_counters_read(rt_ctx* ctx, rt_counters* out);          /* synchronises the stream */
+/* When on, every pipeline launch is bracketed by HIP events on the context's stream; rt_timing_read synchronises,
+ * returns the sums since the last read and clears them.  Off by default (events cost a little host time). */
+int rt_ctx_set_timing(rt_ctx* ctx, int on);
+int rt_timing_read(rt_ctx* ctx, rt_timing* out);
 /* When on, trace / render launches use the instrumented kernels that also count BVH node and primitive
  * record fetches per ray class (slower; for roofline accounting and tests). */
 int rt_ctx_set_counting(rt_ctx* ctx, int on);
@@ -175,6 +200,10 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* cam, int max_scatters, do
                          uint8_t* rgb_host, int32_t* hit_id_host_or_null);
 int rt_trace_primary_host(rt_ctx* ctx, const rt_camera* cam, int32_t* hit_id_host, double* dist_host);
 int rt_trace_rays_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, int32_t* hit_id_host, double* dist_host);
+int rt_trace_rays_full_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, double* records16_host);
+int rt_shade_hits_host(rt_ctx* ctx, const double* hits8_host, const double* view3_host, uint64_t n, uint8_t* rgb_host);
+int rt_render_samples_host(rt_ctx* ctx, const rt_camera* cam, int samples_per_pixel, uint32_t seed, int max_scatters,
+                           double min_scatter_intensity, uint8_t* rgb_host);
 
 /* 256-entry table of the reference's gamma_encode lambda (raytracer.cpp:428-432). */
 int rt_gamma_lut(uint8_t lut[256]);

@@ -57,6 +57,12 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Timing(C.Structure):
+    _fields_ = [("primary_ms", C.c_double), ("shadow_ms", C.c_double), ("resolve_ms", C.c_double), ("bounce_ms", C.c_double),
+                ("primary_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("resolve_launches", C.c_uint32),
+                ("bounce_launches", C.c_uint32)]
+
+
 # every symbol include/rt_hip.h declares: (name, restype, argtypes)
 _VP, _I32, _U32, _U64, _D = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_double
 _DP = C.POINTER(C.c_double)
@@ -82,6 +88,9 @@ SYMBOLS = [
     ("rt_trace_primary", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP, _VP]),
     ("rt_trace_rays", C.c_int, [_VP, _VP, _U64, _VP, _VP]),
     ("rt_shade_rays", C.c_int, [_VP, _VP, _U64, _VP]),
+    ("rt_trace_rays_full", C.c_int, [_VP, _VP, _U64, _VP]),
+    ("rt_shade_hits", C.c_int, [_VP, _VP, _VP, _U64, _VP]),
+    ("rt_render_samples", C.c_int, [_VP, C.POINTER(Camera), Rect, C.c_int, _U32, C.c_int, _D, _VP]),
     ("rt_render_rect", C.c_int, [_VP, C.POINTER(Camera), Rect, C.c_int, _D, _VP, _VP]),
     ("rt_render_tiles", C.c_int, [_VP, C.POINTER(Camera), Tiling, C.c_int, C.c_int, _D, _VP]),
     ("rt_assemble_tiles", C.c_int, [_VP, Tiling, _VP, _VP]),
@@ -90,9 +99,14 @@ SYMBOLS = [
     ("rt_counters_reset", C.c_int, [_VP]),
     ("rt_counters_read", C.c_int, [_VP, C.POINTER(Counters)]),
     ("rt_ctx_set_counting", C.c_int, [_VP, C.c_int]),
+    ("rt_ctx_set_timing", C.c_int, [_VP, C.c_int]),
+    ("rt_timing_read", C.c_int, [_VP, C.POINTER(Timing)]),
     ("rt_render_frame_host", C.c_int, [_VP, C.POINTER(Camera), C.c_int, _D, _VP, _VP]),
     ("rt_trace_primary_host", C.c_int, [_VP, C.POINTER(Camera), _VP, _VP]),
     ("rt_trace_rays_host", C.c_int, [_VP, _VP, _U64, _VP, _VP]),
+    ("rt_trace_rays_full_host", C.c_int, [_VP, _VP, _U64, _VP]),
+    ("rt_shade_hits_host", C.c_int, [_VP, _VP, _VP, _U64, _VP]),
+    ("rt_render_samples_host", C.c_int, [_VP, C.POINTER(Camera), C.c_int, _U32, C.c_int, _D, _VP]),
     ("rt_gamma_lut", C.c_int, [_VP]),
     ("rt_strerror", C.c_char_p, [C.c_int]),
     ("rt_last_error", C.c_char_p, []),
@@ -285,6 +299,15 @@ class Context:
     def set_counting(self, on):
         _check(lib().rt_ctx_set_counting(self.h, 1 if on else 0))
 
+    def set_timing(self, on):
+        _check(lib().rt_ctx_set_timing(self.h, 1 if on else 0))
+
+    def timing(self):
+        """Device milliseconds and launch counts per pipeline stage since the last call (synchronises)."""
+        t = Timing()
+        _check(lib().rt_timing_read(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Timing._fields_}
+
     def reset_counters(self):
         _check(lib().rt_counters_reset(self.h))
 
@@ -302,6 +325,15 @@ class Context:
 
     def shade_rays_dev(self, rays_ptr, n, rgb_ptr):
         _check(lib().rt_shade_rays(self.h, rays_ptr, n, rgb_ptr))
+
+    def trace_rays_full_dev(self, rays_ptr, n, records_ptr):
+        _check(lib().rt_trace_rays_full(self.h, rays_ptr, n, records_ptr))
+
+    def shade_hits_dev(self, hits_ptr, view_ptr, n, rgb_ptr):
+        _check(lib().rt_shade_hits(self.h, hits_ptr, view_ptr, n, rgb_ptr))
+
+    def render_samples_dev(self, cam, rect, spp, seed, rgb_ptr, max_scatters=0, min_scatter_intensity=0.0):
+        _check(lib().rt_render_samples(self.h, C.byref(cam), Rect(*rect), spp, seed, max_scatters, min_scatter_intensity, rgb_ptr))
 
     def render_rect_dev(self, cam, rect, rgb_ptr, ids_ptr=None, max_scatters=0, min_scatter_intensity=0.0):
         _check(lib().rt_render_rect(self.h, C.byref(cam), Rect(*rect), max_scatters, min_scatter_intensity, rgb_ptr, ids_ptr))
@@ -331,6 +363,26 @@ class Context:
         dist = np.empty(len(rays6), dtype=np.float64)
         _check(lib().rt_trace_rays_host(self.h, _ptr(rays6), len(rays6), _ptr(ids), _ptr(dist)))
         return ids, dist
+
+    def trace_rays_full(self, rays6):
+        """(n, 16) float64 records: hit flag, id, distance, point, normal, reflected direction, u, v, 0, 0."""
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        rec = np.empty((len(rays6), 16), dtype=np.float64)
+        _check(lib().rt_trace_rays_full_host(self.h, _ptr(rays6), len(rays6), _ptr(rec)))
+        return rec
+
+    def shade_hits(self, hits8, view3):
+        hits8 = np.ascontiguousarray(hits8, dtype=np.float64).reshape(-1, 8)
+        view3 = np.ascontiguousarray(view3, dtype=np.float64).reshape(-1, 3)
+        assert len(hits8) == len(view3)
+        rgb = np.empty((len(hits8), 3), dtype=np.uint8)
+        _check(lib().rt_shade_hits_host(self.h, _ptr(hits8), _ptr(view3), len(hits8), _ptr(rgb)))
+        return rgb
+
+    def render_samples(self, cam, spp, seed=1, max_scatters=2, min_scatter_intensity=0.0):
+        rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
+        _check(lib().rt_render_samples_host(self.h, C.byref(cam), spp, seed, max_scatters, min_scatter_intensity, _ptr(rgb)))
+        return rgb
 
 
 def tiles_per_rank(tiling):

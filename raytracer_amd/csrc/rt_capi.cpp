@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "rt_device.h"
 #include "rt_scene.h"
@@ -46,14 +47,31 @@ struct rt_ctx {
     bool have_scene = false;
     DevScene sc{};
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
-    rt_light* d_lights = nullptr; uint8_t* d_gamma = nullptr; rt_counters* d_ctr = nullptr;
+    rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
+    uint8_t* d_gamma = nullptr;            // 256 bytes of the display transfer table, then 256 bytes of identity
     unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
     uint32_t queue_used = kQueueSlots;     // slots consumed since the last zeroing
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
     int refill_min = RT_REFILL_MIN;
+    // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_kind;             // one entry per recorded launch; events 2k and 2k+1 of the pool belong to it
+    hipEvent_t timing_event(size_t i) {
+        while (ev_pool.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev_pool.push_back(e); }
+        return ev_pool[i];
+    }
+    void mark_begin(int kind) {
+        if (!timing) return;
+        if (hipEvent_t e = timing_event(2 * ev_kind.size())) { (void)hipEventRecord(e, stream); ev_kind.push_back(kind); }
+    }
+    void mark_end() {
+        if (!timing || ev_kind.empty()) return;
+        if (hipEvent_t e = timing_event(2 * ev_kind.size() - 1)) (void)hipEventRecord(e, stream);
+    }
     // grow-only scratch of the *_host conveniences
-    void* scratch[4] = { nullptr, nullptr, nullptr, nullptr };    // 0..2 host conveniences, 3 frame working set
-    size_t scratch_bytes[4] = { 0, 0, 0, 0 };
+    void* scratch[6] = {};    // 0..2 host conveniences, 3 frame working set, 4 one sample's colours, 5 sample sums
+    size_t scratch_bytes[6] = {};
 
     void free_scene() {
         if (d_nodes) (void)hipFree(d_nodes);
@@ -90,6 +108,7 @@ void to_dev_camera(const rt_camera& c, DevCamera& d) {
     else                             { d.eff_h = c.sensor_h; d.eff_w = d.eff_h * aspect_img; }
     d.focal = c.focal;
     d.width = static_cast<double>(c.width); d.height = static_cast<double>(c.height);
+    d.jitter_seed = 0;
 }
 
 int rect_map(const rt_camera* cam, rt_rect r, PixelMap& pm, uint32_t& n_blocks) {
@@ -245,8 +264,12 @@ int rt_ctx_create(int device, rt_ctx** out) {
             if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_min = v; }
         }
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 256);
-    if (e == hipSuccess) { uint8_t lut[256]; rt_gamma_table(lut); e = hipMemcpy(c->d_gamma, lut, 256, hipMemcpyHostToDevice); }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 512);
+    if (e == hipSuccess) {
+        uint8_t lut[512]; rt_gamma_table(lut);
+        for (int k = 0; k < 256; ++k) lut[256 + k] = static_cast<uint8_t>(k);
+        e = hipMemcpy(c->d_gamma, lut, 512, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         const std::string msg = std::string("context creation: ") + hipGetErrorString(e);
         rt_ctx_destroy(c);
@@ -266,6 +289,7 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     if (ctx->d_gamma) (void)hipFree(ctx->d_gamma);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     for (void* p : ctx->scratch) if (p) (void)hipFree(p);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RT_OK;
@@ -286,6 +310,29 @@ int rt_ctx_use_own_stream(rt_ctx* ctx) {
 int rt_ctx_synchronize(rt_ctx* ctx) {
     if (int rc = use(ctx)) return rc;
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_ctx_set_timing(rt_ctx* ctx, int on) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->timing = on != 0;
+    if (!ctx->timing) ctx->ev_kind.clear();
+    return RT_OK;
+}
+
+int rt_timing_read(rt_ctx* ctx, rt_timing* out) {
+    if (!out) return fail(RT_ERR_INVALID, "null argument");
+    if (int rc = use(ctx)) return rc;
+    std::memset(out, 0, sizeof(*out));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    double* ms[4] = { &out->primary_ms, &out->shadow_ms, &out->resolve_ms, &out->bounce_ms };
+    uint32_t* n[4] = { &out->primary_launches, &out->shadow_launches, &out->resolve_launches, &out->bounce_launches };
+    for (size_t k = 0; k < ctx->ev_kind.size(); ++k) {
+        float t = 0.0f;
+        RT_HIP(hipEventElapsedTime(&t, ctx->ev_pool[2*k], ctx->ev_pool[2*k + 1]));
+        *ms[ctx->ev_kind[k]] += t; ++*n[ctx->ev_kind[k]];
+    }
+    ctx->ev_kind.clear();
     return RT_OK;
 }
 
@@ -330,6 +377,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.n_slots = static_cast<uint32_t>(scene->n_slots);
     d.n_loose = static_cast<uint32_t>(scene->n_loose);
     d.n_lights = static_cast<uint32_t>(scene->lights.size());
+    d.n_prims = static_cast<uint32_t>(scene->prims.size());
     // round the radius up: the padding must not shrink through the conversion
     d.radius = std::nextafterf(static_cast<float>(scene->info.radius), INFINITY);
     if (!std::isfinite(d.radius)) d.radius = 3.0e38f;
@@ -380,14 +428,20 @@ int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t 
     ctx->queue_used = kQueueSlots;      // a captured or replayed sequence must not depend on earlier calls: always re-zero
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, &q)) return rc;
+    ctx->mark_begin(0);
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
                              &fb, ctx->d_ctr, q, ctx->refill_min));
+    ctx->mark_end();
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
         if (int rc = next_queue(ctx, &q)) return rc;
+        ctx->mark_begin(1);
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
+        ctx->mark_end();
+        ctx->mark_begin(2);
         RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &fb, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
+        ctx->mark_end();
     }
     return RT_OK;
 }
@@ -412,7 +466,7 @@ int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit
     if (int rc = need_scene(ctx)) return rc;
     if (n && !rays6_dev) return fail(RT_ERR_INVALID, "null rays");
     if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
-    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, hit_id_dev, dist_dev, nullptr, ctx->d_ctr));
+    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, hit_id_dev, dist_dev, nullptr, nullptr, ctx->d_ctr));
     return RT_OK;
 }
 
@@ -420,12 +474,70 @@ int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb
     if (int rc = need_scene(ctx)) return rc;
     if (n && (!rays6_dev || !rgb_dev)) return fail(RT_ERR_INVALID, "null argument");
     if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
-    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 1, nullptr, nullptr, rgb_dev, ctx->d_ctr));
+    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 1, nullptr, nullptr, rgb_dev, nullptr, ctx->d_ctr));
     return RT_OK;
 }
 
+int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double* records16_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n && (!rays6_dev || !records16_dev)) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, nullptr, nullptr, nullptr, records16_dev, ctx->d_ctr));
+    return RT_OK;
+}
+
+int rt_shade_hits(rt_ctx* ctx, const double* hits8_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n && (!hits8_dev || !view3_dev || !rgb_dev)) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many hits for one launch");
+    RT_HIP(rt_launch_shade_hits(ctx->stream, &ctx->sc, hits8_dev, view3_dev, n, rgb_dev, ctx->d_ctr));
+    return RT_OK;
+}
+
+namespace {
+
+// Display transfer on or off for the launches that follow (kernel arguments are copied at launch).
+struct LinearOutput {
+    rt_ctx* ctx;
+    LinearOutput(rt_ctx* c, bool linear) : ctx(c) { if (linear) ctx->sc.gamma = ctx->d_gamma + 256; }
+    ~LinearOutput() { ctx->sc.gamma = ctx->d_gamma; }
+};
+
+int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
+                uint8_t* rgb_dev, int32_t* hit_id_dev, uint32_t jitter_seed, bool linear);
+
+} // namespace
+
 int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
                    uint8_t* rgb_dev, int32_t* hit_id_dev) {
+    return render_rect(ctx, cam, rect, max_scatters, min_scatter_intensity, rgb_dev, hit_id_dev, 0, false);
+}
+
+int rt_render_samples(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int samples_per_pixel, uint32_t seed, int max_scatters,
+                      double min_scatter_intensity, uint8_t* rgb_dev) {
+    if (samples_per_pixel <= 1) return render_rect(ctx, cam, rect, max_scatters, min_scatter_intensity, rgb_dev, nullptr, 0, false);
+    if (samples_per_pixel > 65536) return fail(RT_ERR_LIMIT, "samples_per_pixel above 65536");
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !rgb_dev || rect.w <= 0 || rect.h <= 0) return fail(RT_ERR_INVALID, "bad camera, rectangle or null output");
+    const size_t n3 = static_cast<size_t>(rect.w) * rect.h * 3;
+    void *d_one = nullptr, *d_sum = nullptr;
+    if (int rc = ctx->need(4, n3, &d_one)) return rc;
+    if (int rc = ctx->need(5, n3 * sizeof(uint32_t), &d_sum)) return rc;
+    for (int s = 0; s < samples_per_pixel; ++s) {
+        // sample 0 goes through the pixel centre (raytracer.cpp:408-409); later ones get a non-zero jitter seed
+        uint32_t js = 0;
+        if (s > 0) { js = (seed ^ 0xA511E9B3u) * 0x9E3779B1u + static_cast<uint32_t>(s) * 0x85EBCA6Bu; if (js == 0) js = 1; }
+        if (int rc = render_rect(ctx, cam, rect, max_scatters, min_scatter_intensity, static_cast<uint8_t*>(d_one), nullptr, js, true)) return rc;
+        RT_HIP(rt_launch_accumulate(ctx->stream, static_cast<const uint8_t*>(d_one), static_cast<uint32_t*>(d_sum), n3, s == 0));
+    }
+    RT_HIP(rt_launch_finish_samples(ctx->stream, static_cast<const uint32_t*>(d_sum), n3, samples_per_pixel, ctx->d_gamma, rgb_dev));
+    return RT_OK;
+}
+
+namespace {
+
+int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
+                uint8_t* rgb_dev, int32_t* hit_id_dev, uint32_t jitter_seed, bool linear) {
     if (int rc = need_scene(ctx)) return rc;
     if (!camera_ok(cam) || !rgb_dev) return fail(RT_ERR_INVALID, "bad camera or null output");
     if (max_scatters < 0) max_scatters = 0;
@@ -433,6 +545,8 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
     PixelMap pm; uint32_t nw = 0;
     if (int rc = rect_map(cam, rect, pm, nw)) return rc;
     DevCamera dc; to_dev_camera(*cam, dc);
+    dc.jitter_seed = jitter_seed;
+    LinearOutput transfer(ctx, linear);
     const size_t n_out = static_cast<size_t>(rect.w) * rect.h;
     if (ctx->sc.n_lights == 0) {
         // no lights: the reference writes an all-black frame without tracing (raytracer.cpp:387-395)
@@ -447,12 +561,16 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
         return RT_OK;
     }
     if (max_scatters > 0) {
+        ctx->mark_begin(3);
         RT_HIP(rt_launch_render_bounce(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, max_scatters, min_scatter_intensity,
                                        rgb_dev, hit_id_dev, ctx->d_ctr));
+        ctx->mark_end();
         return RT_OK;
     }
     return run_pipeline(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev);
 }
+
+} // namespace
 
 int32_t rt_tile_count(rt_tiling t) {
     if (t.tile <= 0 || t.width <= 0 || t.height <= 0) return 0;
@@ -549,6 +667,50 @@ int rt_trace_rays_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, int32_
     if (int rc = rt_trace_rays(ctx, static_cast<const double*>(d_rays), n, static_cast<int32_t*>(d_ids), static_cast<double*>(d_dist))) return rc;
     if (hit_id_host) RT_HIP(hipMemcpyAsync(hit_id_host, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (dist_host) RT_HIP(hipMemcpyAsync(dist_host, d_dist, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_render_samples_host(rt_ctx* ctx, const rt_camera* cam, int samples_per_pixel, uint32_t seed, int max_scatters,
+                           double min_scatter_intensity, uint8_t* rgb_host) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !rgb_host) return fail(RT_ERR_INVALID, "bad camera or null output");
+    const size_t px = static_cast<size_t>(cam->width) * cam->height;
+    void* d_rgb = nullptr;
+    if (int rc = ctx->need(0, px * 3, &d_rgb)) return rc;
+    const rt_rect full = { 0, 0, cam->width, cam->height };
+    if (int rc = rt_render_samples(ctx, cam, full, samples_per_pixel, seed, max_scatters, min_scatter_intensity, static_cast<uint8_t*>(d_rgb))) return rc;
+    RT_HIP(hipMemcpyAsync(rgb_host, d_rgb, px * 3, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace_rays_full_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, double* records16_host) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n == 0) return RT_OK;
+    if (!rays6_host || !records16_host) return fail(RT_ERR_INVALID, "null argument");
+    void *d_rays = nullptr, *d_rec = nullptr;
+    if (int rc = ctx->need(0, n * 6 * sizeof(double), &d_rays)) return rc;
+    if (int rc = ctx->need(2, n * 16 * sizeof(double), &d_rec)) return rc;
+    RT_HIP(hipMemcpyAsync(d_rays, rays6_host, n * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rt_trace_rays_full(ctx, static_cast<const double*>(d_rays), n, static_cast<double*>(d_rec))) return rc;
+    RT_HIP(hipMemcpyAsync(records16_host, d_rec, n * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_shade_hits_host(rt_ctx* ctx, const double* hits8_host, const double* view3_host, uint64_t n, uint8_t* rgb_host) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n == 0) return RT_OK;
+    if (!hits8_host || !view3_host || !rgb_host) return fail(RT_ERR_INVALID, "null argument");
+    void *d_hits = nullptr, *d_view = nullptr, *d_rgb = nullptr;
+    if (int rc = ctx->need(0, n * 8 * sizeof(double), &d_hits)) return rc;
+    if (int rc = ctx->need(1, n * 3 * sizeof(double), &d_view)) return rc;
+    if (int rc = ctx->need(2, n * 3, &d_rgb)) return rc;
+    RT_HIP(hipMemcpyAsync(d_hits, hits8_host, n * 8 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipMemcpyAsync(d_view, view3_host, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rt_shade_hits(ctx, static_cast<const double*>(d_hits), static_cast<const double*>(d_view), n, static_cast<uint8_t*>(d_rgb))) return rc;
+    RT_HIP(hipMemcpyAsync(rgb_host, d_rgb, n * 3, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }

@@ -21,7 +21,7 @@ struct DevScene {
     const rt_mat_rec*  mats;       // by primitive id
     const rt_light*    lights;
     const uint8_t*     gamma;      // 256-entry table
-    uint32_t n_nodes, n_slots, n_loose, n_lights;
+    uint32_t n_nodes, n_slots, n_loose, n_lights, n_prims;
     float radius;                  // max |coordinate| of the scene: scales the box padding
 };
 
@@ -30,6 +30,7 @@ struct DevCamera {                 // persp_camera.h:29-36 with the sensor-fit b
     double rot[9];
     double eff_w, eff_h, focal;
     double width, height;
+    uint32_t jitter_seed;          // 0: pixel centres; otherwise seeds a per-pixel sub-pixel offset
 };
 
 // How blocks map to pixels and output slots.
@@ -64,7 +65,11 @@ hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera*
                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
 hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, uint32_t n_batch, int first, int last, uint8_t* rgb);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
-                                int32_t* ids, double* dist, uint8_t* rgb, rt_counters* ctr);
+                                int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr);
+hipError_t rt_launch_accumulate(hipStream_t st, const uint8_t* rgb, uint32_t* acc, size_t n, int first);
+hipError_t rt_launch_finish_samples(hipStream_t st, const uint32_t* acc, size_t n, int spp, const uint8_t* gamma, uint8_t* rgb);
+hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
+                                uint8_t* rgb, rt_counters* ctr);
 hipError_t rt_launch_render_bounce(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_waves,
                                    int counting, int max_scatters, double min_si, uint8_t* rgb, int32_t* ids, rt_counters* ctr);
 hipError_t rt_launch_assemble(hipStream_t st, int width, int height, int tile, int tiles_x, int n_ranks, int tiles_per_rank,

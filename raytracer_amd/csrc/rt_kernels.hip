@@ -33,9 +33,11 @@ struct HitD {            // full surface record of one hit (shading inputs)
     double px, py, pz;
     double nx, ny, nz;
     double rx, ry, rz;   // mirror direction
+    double u, v;         // surface coordinates (only filled on request)
 };
 
 DEV double dsqrt(double x) { return __builtin_sqrt(x); }
+DEV double clamp_unit(double v) { return (v < -1.0) ? -1.0 : ((1.0 < v) ? 1.0 : v); }
 
 // ---- leaf intersectors -----------------------------------------------------------------------------
 // Each "local" solver works in the primitive's own frame and returns the local hit point (and, when FULL,
@@ -131,7 +133,8 @@ template <int N> DEV void load_rec(const rt_prim_rec* rec, double (&c)[18]) {
 
 // One primitive record against one ray.  The three families (ellipsoid / planar / rotated-scaled box frame)
 // are laid out so that a wave holding a mix of kinds serialises only the family-specific middle part.
-template <bool FULL> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, const RayD& r, HitD& h) {
+template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, const RayD& r, HitD& h) {
+    const double pi = 3.14159265358979323846;
     double c[18];
     double px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0;
     if (kind == RT_SPHERE) {
@@ -157,6 +160,13 @@ template <bool FULL> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, 
             const double wx = l0 * c[6], wy = l1 * c[7], wz = l2 * c[8];
             const double len = dsqrt(wx*wx + wy*wy + wz*wz);
             nx = wx/len; ny = wy/len; nz = wz/len;
+        }
+        if (UV) {       // spherical mapping of the local point, mesh.cpp:669-679
+            double ux = l0, uy = l1, uz = l2;
+            const double plen = dsqrt(ux*ux + uy*uy + uz*uz);
+            if (plen > 1e-15) { ux /= plen; uy /= plen; uz /= plen; }
+            h.u = 0.5 + atan2(uz, ux) / (2.0 * pi);
+            h.v = 0.5 - asin(clamp_unit(uy)) / pi;
         }
     } else if (kind == RT_PLANE || kind == RT_TRIANGLE) {
         // Plane::intersect (parallelogram P0 + u e1 + v e2), mesh.cpp:855-886, and the triangle extension
@@ -190,6 +200,7 @@ template <bool FULL> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, 
         px = c[9]  + (c[12]*u + c[15]*v + zx);
         py = c[10] + (c[13]*u + c[16]*v + zy);
         pz = c[11] + (c[14]*u + c[17]*v + zz);
+        if (UV) { h.u = u; h.v = v; }
     } else if (kind == RT_CUBE || kind == RT_CYLINDER) {
         // c: T[0..2], R[3..11] row-major, S[12..14], 1/S[15..17].  World ray into the unit frame
         // (mesh.cpp:171-180), local solve, local hit back to the world (mesh.cpp:223-233).
@@ -216,6 +227,18 @@ template <bool FULL> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, 
             const double wz = c[9]*m0 + c[10]*m1 + c[11]*m2;
             const double len = dsqrt(wx*wx + wy*wy + wz*wz);
             nx = wx/len; ny = wy/len; nz = wz/len;
+        }
+        if (UV) {
+            if (kind == RT_CUBE) {          // per-face planar mapping, mesh.cpp:262-278
+                if (__builtin_fabs(nl[0]) > 0.5)      { h.u = 0.5 * (pl[2] + 1.0); h.v = 0.5 * (pl[1] + 1.0); }
+                else if (__builtin_fabs(nl[1]) > 0.5) { h.u = 0.5 * (pl[0] + 1.0); h.v = 0.5 * (pl[2] + 1.0); }
+                else                                  { h.u = 0.5 * (pl[0] + 1.0); h.v = 0.5 * (pl[1] + 1.0); }
+            } else if (__builtin_fabs(nl[2]) < 0.5) {   // cylinder side: unwrap, mesh.cpp:497-512
+                h.u = (atan2(pl[1], pl[0]) + pi) / (2.0 * pi);
+                h.v = 0.5 * (pl[2] + 1.0);
+            } else {
+                h.u = 0.5 * (pl[0] + 1.0); h.v = 0.5 * (pl[1] + 1.0);
+            }
         }
     } else {
         return false;
@@ -522,6 +545,22 @@ DEV void primary_ray(const DevCamera& cam, double px, double py, RayD& r) {
     r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
 }
 
+// Pixel (x, y): centre (x + 0.5, y + 0.5) (raytracer.cpp:131-134), plus - for samples after the first - a sub-pixel
+// offset in [-0.5, 0.5)^2.  The reference draws that offset from a random_device-seeded mt19937
+// (raytracer.cpp:398-409); here it is a counter-based hash of (seed, pixel), so a frame is reproducible.
+DEV void primary_ray(const DevCamera& cam, int x, int y, RayD& r) {
+    double jx = 0.0, jy = 0.0;
+    if (cam.jitter_seed) {
+        uint32_t h = cam.jitter_seed * 0x9E3779B1u ^ (static_cast<uint32_t>(x) * 0x85EBCA77u) ^ (static_cast<uint32_t>(y) * 0xC2B2AE3Du);
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        uint32_t g = h * 0x9E3779B1u + 0x7F4A7C15u;
+        g ^= g >> 16; g *= 0x7FEB352Du; g ^= g >> 15; g *= 0x846CA68Bu; g ^= g >> 16;
+        jx = static_cast<double>(h) * (1.0 / 4294967296.0) - 0.5;
+        jy = static_cast<double>(g) * (1.0 / 4294967296.0) - 0.5;
+    }
+    primary_ray(cam, static_cast<double>(x) + 0.5 + jx, static_cast<double>(y) + 0.5 + jy, r);
+}
+
 // ---- pixel enumeration -------------------------------------------------------------------------
 
 DEV uint32_t compact1by1(uint32_t v) {        // even bits of v packed together (Z-order decode)
@@ -675,7 +714,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     if (p.valid) {
                         out = p.out;
                         if (MODE == 0) {
-                            RayD r; primary_ray(cam, static_cast<double>(p.x) + 0.5, static_cast<double>(p.y) + 0.5, r);
+                            RayD r; primary_ray(cam, p.x, p.y, r);
                             w.start(sc, r, my_stack, deep.e, 0.0);
                             ++n_cast;
                             state = w.done() ? DONE : TRAV;
@@ -734,7 +773,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, FrameBufs fb, uint
 template <bool COUNT, bool SHADE>
 __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __restrict__ rays, uint64_t n,
                                                    int32_t* __restrict__ ids, double* __restrict__ dist,
-                                                   uint8_t* __restrict__ rgb, rt_counters* ctr) {
+                                                   uint8_t* __restrict__ rgb, double* __restrict__ records, rt_counters* ctr) {
     uint2* my_stack = nullptr;
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
     bool hit = false;
@@ -749,6 +788,16 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
         hit = traverse<0, COUNT>(sc, r, my_stack, 0.0, b, vn, vp);
         if (ids) ids[i] = b.id;
         if (dist) dist[i] = b.dist;
+        if (records) {      // the Hit of the reference (utils.h:68-112): 16 doubles per ray
+            double* o = records + i * 16;
+            HitD h; h.u = 0.0; h.v = 0.0;
+            if (hit) { const rt_prim_rec* rec = sc.recs + b.slot; hit_record<true, true>(rec, rec->kind, r, h); }
+            o[0] = hit ? 1.0 : 0.0; o[1] = static_cast<double>(b.id); o[2] = b.dist;
+            o[3] = hit ? h.px : 0.0; o[4] = hit ? h.py : 0.0; o[5] = hit ? h.pz : 0.0;
+            o[6] = hit ? h.nx : 0.0; o[7] = hit ? h.ny : 0.0; o[8] = hit ? h.nz : 0.0;
+            o[9] = hit ? h.rx : 0.0; o[10] = hit ? h.ry : 0.0; o[11] = hit ? h.rz : 0.0;
+            o[12] = hit ? h.u : 0.0; o[13] = hit ? h.v : 0.0; o[14] = 0.0; o[15] = 0.0;
+        }
         if (SHADE) {
             uint32_t c = 0;
             if (hit) {
@@ -770,6 +819,25 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
     }
 }
 
+// RayTracer::shade for caller-supplied hits: 8 doubles each (point, normal, primitive id, unused) and a view origin
+// (3 doubles) per hit; linear 8-bit colour out.
+__global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __restrict__ hits, const double* __restrict__ view,
+                                                   uint64_t n, uint8_t* __restrict__ rgb, rt_counters* ctr) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
+    ShadeCounters sctr = { 0, 0, 0 };
+    if (i < n) {
+        HitD h;
+        h.px = hits[i*8]; h.py = hits[i*8 + 1]; h.pz = hits[i*8 + 2];
+        h.nx = hits[i*8 + 3]; h.ny = hits[i*8 + 4]; h.nz = hits[i*8 + 5];
+        const double idf = hits[i*8 + 6];
+        uint32_t c = 0;
+        if (idf >= 0.0 && idf < static_cast<double>(sc.n_prims))
+            c = shade<false>(sc, h, static_cast<int32_t>(idf), view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+        rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
+    }
+    add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, F_SHADOW, sctr.shadow_rays);
+}
+
 // The whole pixel pipeline of render_unaccelerated_ppm in one lane (raytracer.cpp:401-438), used when mirror
 // bounces are on: trace_ray_recursive (raytracer.cpp:281-371) unrolled into a loop - walk down the mirror chain
 // keeping each level's local colour, Fresnel weight and tint, then fold the 8-bit blends back up.
@@ -784,7 +852,7 @@ __global__ void __launch_bounds__(64) k_render_bounce(DevScene sc, DevCamera cam
     uint32_t vn = 0, vp = 0, bounce_rays = 0;
     bool primary_hit = false;
     if (p.valid) {
-        RayD r; primary_ray(cam, static_cast<double>(p.x) + 0.5, static_cast<double>(p.y) + 0.5, r);
+        RayD r; primary_ray(cam, p.x, p.y, r);
         double   lvl_fr[RT_MAX_SCATTERS];
         uint32_t lvl_local[RT_MAX_SCATTERS + 1];
         uint32_t lvl_tint[RT_MAX_SCATTERS];      // albedo | metallic flag << 24
@@ -868,6 +936,32 @@ __global__ void __launch_bounds__(256) k_assemble_tiles(int width, int height, i
 
 // ---- host-callable launchers (called from rt_capi.cpp) ---------------------------------------------
 
+// Multi-sample frames: per-sample linear 8-bit colours are summed per channel, and the mean is rounded and gamma
+// encoded once (raytracer.cpp:419-436).
+__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ acc, size_t n, int first) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) acc[i] = (first ? 0u : acc[i]) + rgb[i];
+}
+
+__global__ void __launch_bounds__(256) k_finish_samples(const uint32_t* __restrict__ acc, size_t n, int spp, const uint8_t* __restrict__ gamma,
+                                                        uint8_t* __restrict__ rgb) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    int m = static_cast<int>(__builtin_round(static_cast<double>(acc[i]) / static_cast<double>(spp)));
+    m = m < 0 ? 0 : (m > 255 ? 255 : m);
+    rgb[i] = gamma[m];
+}
+
+extern "C" hipError_t rt_launch_accumulate(hipStream_t st, const uint8_t* rgb, uint32_t* acc, size_t n, int first) {
+    if (n) hipLaunchKernelGGL(k_accumulate, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, st, rgb, acc, n, first);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_finish_samples(hipStream_t st, const uint32_t* acc, size_t n, int spp, const uint8_t* gamma, uint8_t* rgb) {
+    if (n) hipLaunchKernelGGL(k_finish_samples, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, st, acc, n, spp, gamma, rgb);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                                         uint32_t n_tiles, uint32_t n_waves, int counting, int32_t* ids, double* dist,
                                         const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
@@ -900,16 +994,23 @@ extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, cons
 }
 
 extern "C" hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
-                                           int32_t* ids, double* dist, uint8_t* rgb, rt_counters* ctr) {
+                                           int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr) {
     const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
     if (nb == 0) return hipSuccess;
     if (shade_it) {
-        if (counting) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, ctr);
-        else          hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, ctr);
+        if (counting) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
+        else          hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
     } else {
-        if (counting) hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, ctr);
-        else          hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, ctr);
+        if (counting) hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
+        else          hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
+                                           uint8_t* rgb, rt_counters* ctr) {
+    const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
+    if (nb) hipLaunchKernelGGL(k_shade_hits, dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
     return hipGetLastError();
 }
 

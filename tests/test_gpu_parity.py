@@ -303,3 +303,95 @@ def test_error_statuses_on_device():
         c.render_tiles_dev(cam, capi.Tiling(32, 32, 24, 2), 0, buf.data_ptr())
     assert e.value.status == -1
     c.close()
+
+
+# ---- whole hit records, shading of supplied hits, multi-sample frames ------------------------------------
+
+@pytest.mark.parametrize("name,cam_id", SHIPPED)
+def test_full_hit_records_against_reference(ctx, name, cam_id):
+    """The 16-double records against the real reference's Hit fields on every 31st primary ray."""
+    g = np.load(os.path.join(GOLDEN, "shipped_%s.npz" % name))
+    sc = capi.Scene.load_json(os.path.join(SCENES, name + ".json"))
+    cam, _ = sc.camera(cam_id)
+    ctx.upload(sc)
+    idx = g["rec_idx"]
+    pxy = np.stack([(idx % cam.width) + 0.5, (idx // cam.width) + 0.5], axis=1)
+    rays = capi.pixel_rays(cam, pxy)
+    rec = ctx.trace_rays_full(rays)
+    want_ids = g["ids"].reshape(-1)[idx].astype(np.int32)
+    hit = want_ids >= 0
+    assert np.array_equal(rec[:, 0] != 0, hit)
+    assert np.array_equal(rec[:, 1].astype(np.int32), want_ids)
+    assert np.all(rec[~hit, 3:] == 0)
+    assert np.array_equal(bits(rec[hit, 3:6]), bits(g["rec_p"][hit]))
+    assert np.array_equal(bits(rec[hit, 6:9]), bits(g["rec_n"][hit]))
+    assert np.array_equal(bits(rec[hit, 9:12]), bits(g["rec_r"][hit]))
+    # u, v go through atan2 / asin, whose device versions may differ from libm in the last bits
+    assert np.abs(rec[hit, 12] - g["rec_u"][hit]).max() <= 1e-12
+    assert np.abs(rec[hit, 13] - g["rec_v"][hit]).max() <= 1e-12
+    assert np.all(rec[:, 14:] == 0)
+
+
+@pytest.mark.parametrize("name,cam_id", [s for s in SHIPPED if s[0] != "200_rand_1_cam"])
+def test_shade_hits_matches_reference_shade(ctx, name, cam_id):
+    g = np.load(os.path.join(GOLDEN, "shipped_%s.npz" % name))
+    sc = capi.Scene.load_json(os.path.join(SCENES, name + ".json"))
+    cam, _ = sc.camera(cam_id)
+    ctx.upload(sc)
+    idx = np.arange(0, cam.width * cam.height, 7)
+    pxy = np.stack([(idx % cam.width) + 0.5, (idx // cam.width) + 0.5], axis=1)
+    rays = capi.pixel_rays(cam, pxy)
+    rec = ctx.trace_rays_full(rays)
+    hits8 = np.zeros((len(idx), 8))
+    hits8[:, 0:6] = rec[:, 3:9]
+    hits8[:, 6] = rec[:, 1]
+    rgb = ctx.shade_hits(hits8, rays[:, 0:3])
+    want = g["shade_linear"].reshape(-1, 3)[idx]
+    assert_rgb_close(rgb, want, max_frac=1e-3)
+
+
+def jitter_offsets(seed, s, xs, ys):
+    """numpy restatement of the per-pixel sub-pixel offset of sample s (s >= 1)."""
+    M = np.uint64(0xFFFFFFFF)
+
+    def mix(h):
+        h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x7FEB352D)) & M
+        h = h ^ (h >> np.uint64(15)); h = (h * np.uint64(0x846CA68B)) & M
+        return h ^ (h >> np.uint64(16))
+    js = ((((seed ^ 0xA511E9B3) * 0x9E3779B1) & 0xFFFFFFFF) + s * 0x85EBCA6B) & 0xFFFFFFFF
+    js = js or 1
+    x = xs.astype(np.uint64); y = ys.astype(np.uint64)
+    h = ((np.uint64(js) * np.uint64(0x9E3779B1)) & M) ^ ((x * np.uint64(0x85EBCA77)) & M) ^ ((y * np.uint64(0xC2B2AE3D)) & M)
+    h = mix(h)
+    gg = mix((h * np.uint64(0x9E3779B1) + np.uint64(0x7F4A7C15)) & M)
+    return h.astype(np.float64) / 4294967296.0 - 0.5, gg.astype(np.float64) / 4294967296.0 - 0.5
+
+
+def test_multi_sample_frame(ctx, oracle):
+    g = np.load(os.path.join(GOLDEN, "synthetic_b.npz"))
+    prims, lights, camd = S.random_scene(int(g["n"]), int(g["seed"]), lights=int(g["n_lights"]))
+    sc = capi.Scene.create(prims, lights)
+    cam = capi.make_camera(**camd)
+    ctx.upload(sc)
+    assert np.array_equal(ctx.render_samples(cam, 1, seed=5, max_scatters=0), ctx.render(cam, max_scatters=0))
+    spp, seed = 3, 77
+    got = ctx.render_samples(cam, spp, seed=seed, max_scatters=0)
+    again = ctx.render_samples(cam, spp, seed=seed, max_scatters=0)
+    assert np.array_equal(got, again)                       # a frame is a pure function of the seed
+    assert not np.array_equal(got, ctx.render_samples(cam, spp, seed=seed + 1, max_scatters=0))
+    W, H = cam.width, cam.height
+    ys, xs = np.divmod(np.arange(W * H), W)
+    osc = oracle.scene(prims, lights)
+    ocam = oracle.camera(camd["location"], camd["direction"], None, camd["focal"], camd["sensor"], camd["res"])
+    acc = np.zeros((W * H, 3))
+    for s in range(spp):
+        jx, jy = (0.0, 0.0) if s == 0 else jitter_offsets(seed, s, xs, ys)
+        rays = oracle.pixel_rays(ocam, np.stack([xs + 0.5 + jx, ys + 0.5 + jy], axis=1))
+        acc += oracle.shade_rays(osc, rays)
+    lut = oracle.gamma_lut()
+    want = lut[np.clip(np.round(acc / spp), 0, 255).astype(np.int64)].reshape(H, W, 3)
+    # a +-1 in one sample's linear colour moves the mean by 1/spp; after rounding and the steep low end of the
+    # transfer curve that can be a few display levels on dark pixels, so compare the linear means instead there
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert (diff > 0).any(-1).mean() < 2e-3
+    assert diff.max() <= 12
