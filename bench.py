@@ -128,14 +128,12 @@ def main():
         def step():
             ctx.render_rect_dev(cam, (0, 0, W, H), frame.data_ptr(), None, args.max_scatters, 0.0)
     else:
-        per_rank = capi.tiles_per_rank(tiling) * args.tile * args.tile * 3
-        local = torch.empty(per_rank, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * per_rank, dtype=torch.uint8, device="cuda") if rank == 0 else None
+        from raytracer_amd import tiles
+        tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
         frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda") if rank == 0 else None
-        glist = list(gathered.split(per_rank)) if rank == 0 else None
         def step():
-            ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
-            dist.gather(local, glist, dst=0)
+            ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
+            gathered = tg.gather()
             if rank == 0:
                 ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
 

@@ -114,6 +114,9 @@ int rt_scene_create(const rt_prim_desc* prims, uint64_t n_prims, const rt_light*
 /* RayTracer::load_from_json (raytracer.h:25, raytracer.cpp:107-121) for the Blender-export format, in
  * linear time, same defaults; the file's cameras are kept and served by rt_scene_camera. */
 int rt_scene_load_json(const char* path, const rt_build_opts* opts_or_null, rt_scene** out);
+/* The same from text already in memory (the per-class readers Cube/Plane/Cylinder/Sphere::read_from_json,
+ * mesh.cpp:52,316,544,707, take text blocks rather than paths). */
+int rt_scene_load_json_text(const char* text, uint64_t len, const rt_build_opts* opts_or_null, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* Borrowed views, valid until rt_scene_destroy. */
@@ -160,7 +163,8 @@ int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb
  * triangles: barycentric edge coordinates), [14..15] zero. */
 int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double* records16_dev);
 /* RayTracer::shade (raytracer.h:34, raytracer.cpp:159-279) for caller-supplied hits: 8 doubles each ([0..2] point,
- * [3..5] normal, [6] primitive id, [7] unused; id outside the scene = miss = black) and the origin of the ray that
+ * [3..5] normal, [6] primitive id, [7] unused; id -2 = a hit that names no primitive, shaded white with the default
+ * material as the reference does; any other id outside the scene = black) and the origin of the ray that
  * produced each hit (3 doubles).  Linear 8-bit colour. */
 int rt_shade_hits(rt_ctx* ctx, const double* hits8_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev);
 /* RayTracer::render_unaccelerated_ppm's pixel loop with samples_per_pixel = 1 (raytracer.cpp:401-438):
@@ -202,6 +206,9 @@ int rt_trace_primary_host(rt_ctx* ctx, const rt_camera* cam, int32_t* hit_id_hos
 int rt_trace_rays_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, int32_t* hit_id_host, double* dist_host);
 int rt_trace_rays_full_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, double* records16_host);
 int rt_shade_hits_host(rt_ctx* ctx, const double* hits8_host, const double* view3_host, uint64_t n, uint8_t* rgb_host);
+/* Cube/Plane/Cylinder/Sphere::intersect (mesh.cpp:159,371,597,795) of ONE primitive, outside any scene, for n rays;
+ * records as rt_trace_rays_full with id 0 on a hit.  Needs no uploaded scene. */
+int rt_intersect_prim_host(rt_ctx* ctx, const rt_prim_desc* prim, const double* rays6_host, uint64_t n, double* records16_host);
 int rt_render_samples_host(rt_ctx* ctx, const rt_camera* cam, int samples_per_pixel, uint32_t seed, int max_scatters,
                            double min_scatter_intensity, uint8_t* rgb_host);
 

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /* TEST INFRASTRUCTURE ONLY - see rt_oracle.h.  Plain-C FP64 restatement of the reference hot path.
  * Every function cites the reference file:line it follows.  Build: oracle/Makefile
  * (gcc -O2 -ffp-contract=off, no fast-math). */
@@ -24,9 +25,12 @@ static void mat_vec(const double M[3][3], const double v[3], double out[3]) {
 /* R = Rz(yaw) * (Ry(pitch) * Rx(roll)) formed by two full 3x3 products, zeros and ones included
  * (build_rotation_matrix_rpy, s2899221/Code/mesh.cpp:122-145). */
 static void rotation_rpy(double roll, double pitch, double yaw, double R[3][3]) {
-    const double cr = cos(roll),  sr = sin(roll);
-    const double cp = cos(pitch), sp = sin(pitch);
-    const double cy = cos(yaw),   sy = sin(yaw);
+    /* sincos(), not sin() and cos(): that is what g++ -O2 makes of the reference's side-by-side calls, and glibc's
+     * sincos() is not bit-identical to its sin() for every angle. */
+    double cr, sr, cp, sp, cy, sy;
+    sincos(roll, &sr, &cr);
+    sincos(pitch, &sp, &cp);
+    sincos(yaw, &sy, &cy);
     const double Z[3][3] = { { cy, -sy, 0 }, { sy, cy, 0 }, { 0, 0, 1 } };
     const double Y[3][3] = { { cp, 0, sp }, { 0, 1, 0 }, { -sp, 0, cp } };
     const double X[3][3] = { { 1, 0, 0 }, { 0, cr, -sr }, { 0, sr, cr } };

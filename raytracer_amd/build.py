@@ -78,9 +78,9 @@ def build(force=False, verbose=False):
         srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp") and not f.endswith("_driver.cpp"))
         if srcs and (force or _stale(HOSTLIB, srcs + headers + [LIB])):
             _run([cc] + COMMON + ["-shared", "-o", HOSTLIB] + srcs + ["-I" + host_dir, "-L" + LIBDIR, "-lrt_hip", "-Wl,-rpath,$ORIGIN"])
-        for drv in ("render_driver", "time_driver"):
+        for drv, name in (("render_driver", "render_driver"), ("time_driver", "time_driver"), ("mirror_check_driver", "mirror_check")):
             src = os.path.join(host_dir, drv + ".cpp")
-            exe = os.path.join(LIBDIR, drv)
+            exe = os.path.join(LIBDIR, name)
             if os.path.exists(src) and (force or _stale(exe, [src, HOSTLIB] + headers)):
                 _run([cc] + COMMON + ["-o", exe, src, "-I" + host_dir, "-L" + LIBDIR, "-lrt_host", "-lrt_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB

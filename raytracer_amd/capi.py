@@ -69,6 +69,7 @@ _DP = C.POINTER(C.c_double)
 SYMBOLS = [
     ("rt_scene_create", C.c_int, [_VP, _U64, _VP, _U32, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_load_json", C.c_int, [C.c_char_p, C.POINTER(BuildOpts), C.POINTER(_VP)]),
+    ("rt_scene_load_json_text", C.c_int, [C.c_char_p, _U64, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_destroy", C.c_int, [_VP]),
     ("rt_scene_get_info", C.c_int, [_VP, C.POINTER(SceneInfo)]),
     ("rt_scene_get_prims", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U64)]),
@@ -106,6 +107,7 @@ SYMBOLS = [
     ("rt_trace_rays_host", C.c_int, [_VP, _VP, _U64, _VP, _VP]),
     ("rt_trace_rays_full_host", C.c_int, [_VP, _VP, _U64, _VP]),
     ("rt_shade_hits_host", C.c_int, [_VP, _VP, _VP, _U64, _VP]),
+    ("rt_intersect_prim_host", C.c_int, [_VP, _VP, _VP, _U64, _VP]),
     ("rt_render_samples_host", C.c_int, [_VP, C.POINTER(Camera), C.c_int, _U32, C.c_int, _D, _VP]),
     ("rt_gamma_lut", C.c_int, [_VP]),
     ("rt_strerror", C.c_char_p, [C.c_int]),
@@ -207,6 +209,14 @@ class Scene:
         opts = BuildOpts(max_leaf, sah_bins)
         h = C.c_void_p()
         _check(lib().rt_scene_load_json(str(path).encode(), C.byref(opts), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_json_text(cls, text, max_leaf=0, sah_bins=0):
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        opts = BuildOpts(max_leaf, sah_bins)
+        h = C.c_void_p()
+        _check(lib().rt_scene_load_json_text(data, len(data), C.byref(opts), C.byref(h)))
         return cls(h)
 
     def close(self):
@@ -369,6 +379,14 @@ class Context:
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
         rec = np.empty((len(rays6), 16), dtype=np.float64)
         _check(lib().rt_trace_rays_full_host(self.h, _ptr(rays6), len(rays6), _ptr(rec)))
+        return rec
+
+    def intersect_prim(self, prim, rays6):
+        """Mesh::intersect of one primitive (a PRIM_DT record) for n rays; (n, 16) records."""
+        prim = np.ascontiguousarray(prim).reshape(1)
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        rec = np.empty((len(rays6), 16), dtype=np.float64)
+        _check(lib().rt_intersect_prim_host(self.h, _ptr(prim), _ptr(rays6), len(rays6), _ptr(rec)))
         return rec
 
     def shade_hits(self, hits8, view3):

@@ -179,6 +179,21 @@ int rt_scene_load_json(const char* path, const rt_build_opts* opts, rt_scene** o
     return RT_OK;
 }
 
+int rt_scene_load_json_text(const char* text, uint64_t len, const rt_build_opts* opts, rt_scene** out) {
+    if (!text || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_LIMIT, "out of memory");
+    try {
+        std::string err;
+        int rc = rt_parse_scene_text(text, static_cast<size_t>(len), s->prims, s->lights, s->cameras, err);
+        if (rc == RT_OK) rc = rt_scene_finalize(s, opts);
+        if (rc != RT_OK) { delete s; return fail(rc, err.empty() ? "scene load failed" : err); }
+    } catch (const std::exception& e) { delete s; return fail(RT_ERR_LIMIT, e.what()); }
+    *out = s;
+    return RT_OK;
+}
+
 int rt_scene_destroy(rt_scene* scene) { delete scene; return RT_OK; }
 
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out) {
@@ -711,6 +726,36 @@ int rt_shade_hits_host(rt_ctx* ctx, const double* hits8_host, const double* view
     RT_HIP(hipMemcpyAsync(d_view, view3_host, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (int rc = rt_shade_hits(ctx, static_cast<const double*>(d_hits), static_cast<const double*>(d_view), n, static_cast<uint8_t*>(d_rgb))) return rc;
     RT_HIP(hipMemcpyAsync(rgb_host, d_rgb, n * 3, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_intersect_prim_host(rt_ctx* ctx, const rt_prim_desc* prim, const double* rays6_host, uint64_t n, double* records16_host) {
+    if (int rc = use(ctx)) return rc;
+    if (!prim) return fail(RT_ERR_INVALID, "null primitive");
+    if (n == 0) return RT_OK;
+    if (!rays6_host || !records16_host) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    rt_prim_rec rec; rt_box64 box;
+    if (rt_make_record(*prim, 0, rec, box) == RT_CLASS_NEVER) {
+        // a primitive no ray can hit (a plane with a degenerate frame or fewer than four corners, mesh.cpp:796-838)
+        for (uint64_t i = 0; i < n; ++i) {
+            double* o = records16_host + i * 16;
+            for (int k = 0; k < 16; ++k) o[k] = 0.0;
+            o[1] = -1.0; o[2] = INFINITY;
+        }
+        return RT_OK;
+    }
+    void *d_rays = nullptr, *d_rec = nullptr, *d_out = nullptr;
+    if (int rc = ctx->need(0, n * 6 * sizeof(double), &d_rays)) return rc;
+    if (int rc = ctx->need(1, sizeof(rec), &d_rec)) return rc;
+    if (int rc = ctx->need(2, n * 16 * sizeof(double), &d_out)) return rc;
+    RT_HIP(hipMemcpyAsync(d_rays, rays6_host, n * 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipMemcpyAsync(d_rec, &rec, sizeof(rec), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));        // rec lives on this frame
+    RT_HIP(rt_launch_intersect_one(ctx->stream, static_cast<const rt_prim_rec*>(d_rec), static_cast<const double*>(d_rays), n,
+                                   static_cast<double*>(d_out)));
+    RT_HIP(hipMemcpyAsync(records16_host, d_out, n * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }

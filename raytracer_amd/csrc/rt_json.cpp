@@ -227,8 +227,13 @@ int rt_parse_scene_file(const char* path, std::vector<rt_prim_desc>& prims, std:
                         std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err) {
     std::string text;
     if (!read_file(path, text)) { err = std::string("cannot open ") + path; return RT_ERR_IO; }
+    return rt_parse_scene_text(text.data(), text.size(), prims, lights, cameras, err);
+}
+
+int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
+                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err) {
     Node root;
-    Parser ps{ text.data(), text.data() + text.size(), std::string() };
+    Parser ps{ text, text + len, std::string() };
     if (!ps.value(root)) {
         // load_from_json reports success even when nothing parses (raytracer.cpp:120); a malformed number is
         // the one case where the reference does not return at all (std::stod throws).

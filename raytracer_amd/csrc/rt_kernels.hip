@@ -519,17 +519,23 @@ DEV uint32_t finish_shade(const rt_mat_rec& m, double lighting) {
 
 // RayTracer::shade, raytracer.cpp:159-279, all lights in order inside one lane (megakernel path).
 template <bool COUNT>
-DEV uint32_t shade(const DevScene& sc, const HitD& h, int32_t id, double view_ox, double view_oy, double view_oz,
-                   uint2* lds_stack, ShadeCounters& ctr) {
+DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec& m, double view_ox, double view_oy, double view_oz,
+                            uint2* lds_stack, ShadeCounters& ctr) {
     if (sc.n_lights == 0) return 0;
     double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);
-    const rt_mat_rec m = sc.mats[id];
     double lighting = 0.0;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const rt_light L = sc.lights[li];
         lighting += light_term<COUNT>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
     }
     return finish_shade(m, lighting);
+}
+
+template <bool COUNT>
+DEV uint32_t shade(const DevScene& sc, const HitD& h, int32_t id, double view_ox, double view_oy, double view_oz,
+                   uint2* lds_stack, ShadeCounters& ctr) {
+    const rt_mat_rec m = sc.mats[id];
+    return shade_material<COUNT>(sc, h, m, view_ox, view_oy, view_oz, lds_stack, ctr);
 }
 
 // Camera::pixelToRay, persp_camera.cpp:94-118 (effective sensor size precomputed on the host).
@@ -819,6 +825,26 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
     }
 }
 
+// Mesh::intersect of one primitive for n rays (mesh.cpp:159, 371, 597, 795): the record layout of k_trace_rays with the
+// primitive id slot holding 0.
+__global__ void __launch_bounds__(64) k_intersect_one(const rt_prim_rec* __restrict__ rec, const double* __restrict__ rays, uint64_t n,
+                                                      double* __restrict__ records) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (i >= n) return;
+    RayD r;
+    r.ox = rays[i*6]; r.oy = rays[i*6 + 1]; r.oz = rays[i*6 + 2];
+    r.dx = rays[i*6 + 3]; r.dy = rays[i*6 + 4]; r.dz = rays[i*6 + 5];
+    r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
+    HitD h; h.u = 0.0; h.v = 0.0;
+    const bool hit = hit_record<true, true>(rec, rec->kind, r, h);
+    double* o = records + i * 16;
+    o[0] = hit ? 1.0 : 0.0; o[1] = hit ? 0.0 : -1.0; o[2] = hit ? h.dist : __builtin_inf();
+    o[3] = hit ? h.px : 0.0; o[4] = hit ? h.py : 0.0; o[5] = hit ? h.pz : 0.0;
+    o[6] = hit ? h.nx : 0.0; o[7] = hit ? h.ny : 0.0; o[8] = hit ? h.nz : 0.0;
+    o[9] = hit ? h.rx : 0.0; o[10] = hit ? h.ry : 0.0; o[11] = hit ? h.rz : 0.0;
+    o[12] = hit ? h.u : 0.0; o[13] = hit ? h.v : 0.0; o[14] = 0.0; o[15] = 0.0;
+}
+
 // RayTracer::shade for caller-supplied hits: 8 doubles each (point, normal, primitive id, unused) and a view origin
 // (3 doubles) per hit; linear 8-bit colour out.
 __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __restrict__ hits, const double* __restrict__ view,
@@ -831,8 +857,14 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
         h.nx = hits[i*8 + 3]; h.ny = hits[i*8 + 4]; h.nz = hits[i*8 + 5];
         const double idf = hits[i*8 + 6];
         uint32_t c = 0;
-        if (idf >= 0.0 && idf < static_cast<double>(sc.n_prims))
+        if (idf >= 0.0 && idf < static_cast<double>(sc.n_prims)) {
             c = shade<false>(sc, h, static_cast<int32_t>(idf), view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+        } else if (idf == -2.0) {
+            // a hit that names no primitive: white, non-metallic, roughness 0.5 (raytracer.cpp:204-208, 250-254, 268-272)
+            rt_mat_rec m;
+            m.metallic = 0.0; m.roughness = 0.5; m.ior = 1.5; m.albedo[0] = 255; m.albedo[1] = 255; m.albedo[2] = 255;
+            c = shade_material<false>(sc, h, m, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+        }
         rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
     }
     add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, F_SHADOW, sctr.shadow_rays);
@@ -1004,6 +1036,12 @@ extern "C" hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, c
         if (counting) hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
         else          hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec* rec, const double* rays, uint64_t n, double* records) {
+    const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
+    if (nb) hipLaunchKernelGGL(k_intersect_one, dim3(nb), dim3(64), 0, st, rec, rays, n, records);
     return hipGetLastError();
 }
 

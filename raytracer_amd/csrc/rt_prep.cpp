@@ -44,9 +44,14 @@ void corners_box(const double T[3], const double R[9], const double S[3], rt_box
 // R = Rz(yaw) * (Ry(pitch) * Rx(roll)) through two full 3x3 products, structural zeros and ones
 // included, so each entry carries the reference's rounding (build_rotation_matrix_rpy, mesh.cpp:122-145).
 void rt_rotation_rpy(double roll, double pitch, double yaw, double R[9]) {
-    const double cr = std::cos(roll),  sr = std::sin(roll);
-    const double cp = std::cos(pitch), sp = std::sin(pitch);
-    const double cy = std::cos(yaw),   sy = std::sin(yaw);
+    // The reference takes cos and sin of each angle side by side (mesh.cpp:123-125); g++ -O2, the build its results
+    // are pinned on, turns each pair into one sincos() call, and glibc's sincos() differs from its sin() in the last
+    // bit for about one angle in a hundred.  Call sincos() outright so that the matrix does not depend on which
+    // compiler built this file.
+    double cr, sr, cp, sp, cy, sy;
+    ::sincos(roll, &sr, &cr);
+    ::sincos(pitch, &sp, &cp);
+    ::sincos(yaw, &sy, &cy);
     const double Z[9] = { cy, -sy, 0, sy, cy, 0, 0, 0, 1 };
     const double Y[9] = { cp, 0, sp, 0, 1, 0, -sp, 0, cp };
     const double X[9] = { 1, 0, 0, 0, cr, -sr, 0, sr, cr };

@@ -40,6 +40,8 @@ void rt_build_bvh(const std::vector<rt_box64>& boxes, uint32_t max_leaf, uint32_
 // rt_json.cpp
 int rt_parse_scene_file(const char* path, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
                         std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err);
+int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
+                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err);
 int rt_parse_camera_file(const char* path, const char* camera_id, rt_camera* out, std::string& err);
 
 // rt_scene.cpp

@@ -228,6 +228,12 @@ def test_tiles_and_subrectangles(ctx):
             ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
             ctx.synchronize()
             assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), full), (tile, n_ranks)
+            # the host restatement of the layout (what the gloo tests exchange) is what the kernels produce
+            from raytracer_amd import tiles as T
+            g_host = gathered.cpu().numpy()
+            for r in range(n_ranks):
+                assert np.array_equal(g_host[r * per:(r + 1) * per], T.pack_rank_tiles(full, tile, n_ranks, r)), (tile, n_ranks, r)
+            assert np.array_equal(T.assemble(g_host, W, H, tile, n_ranks), full)
         x0, y0, w, h = 37, 21, 101, 77
         sub = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda")
         sid = torch.empty(h * w, dtype=torch.int32, device="cuda")
@@ -395,3 +401,27 @@ def test_multi_sample_frame(ctx, oracle):
     diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
     assert (diff > 0).any(-1).mean() < 2e-3
     assert diff.max() <= 12
+
+
+@pytest.mark.parametrize("kind", [S.CUBE, S.PLANE, S.CYLINDER, S.SPHERE])
+def test_single_primitive_intersect_against_reference(ctx, kind):
+    """Mesh::intersect of lone primitives built through the reference's public constructors: random rays plus
+    origins inside, axis-parallel and zero directions, zero scales and degenerate corners."""
+    g = np.load(os.path.join(GOLDEN, "single_prims.npz"))
+    k = S.KIND_NAMES[kind].lower()
+    for t in range(len(g[k + "_params"])):
+        prim = np.zeros(1, dtype=S.PRIM_DT)
+        prim["kind"] = kind
+        prim["q"][0] = g[k + "_params"][t]
+        prim["alpha"] = 1.0; prim["roughness"] = 0.5; prim["ior"] = 1.5; prim["albedo"] = 1.0
+        rec = ctx.intersect_prim(prim, g[k + "_rays"][t])
+        assert np.array_equal(rec[:, 0] != 0, g[k + "_hit"][t] == 1), (k, t)
+        m = rec[:, 0] != 0
+        for f, cols in (("dist", slice(2, 3)), ("p", slice(3, 6)), ("n", slice(6, 9)), ("r", slice(9, 12))):
+            a, b = rec[m, cols].reshape(-1), np.asarray(g[k + "_" + f][t][m], dtype=np.float64).reshape(-1)
+            same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (k, t, f)
+        for f, col in (("u", 12), ("v", 13)):
+            a, b = rec[m, col], g[k + "_" + f][t][m]
+            assert (np.isnan(a) == np.isnan(b)).all() and np.nanmax(np.abs(a - b), initial=0.0) <= 1e-12, (k, t, f)
+        assert np.all(rec[~m, 1] == -1) and np.all(np.isinf(rec[~m, 2]))

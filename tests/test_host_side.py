@@ -273,3 +273,18 @@ def test_bvh_walk_with_loose_degenerate_and_tied_primitives(oracle):
     want = (a["hit"] == 1) & (a["dist"] > 1e-4) & (a["dist"] < L - 1e-4)
     got = oracle.bvh_occluded(osc, b, rays_n, L)
     assert np.array_equal(got.astype(bool), want)
+
+
+@pytest.mark.parametrize("kind", [S.CUBE, S.PLANE, S.CYLINDER, S.SPHERE])
+def test_library_aabbs_of_constructed_primitives(kind):
+    """compute_aabb of primitives built through the reference's constructors, bit for bit: this pins the library's
+    own rotation matrices (the reference's build, g++ -O2, evaluates each angle with one sincos() call)."""
+    g = np.load(os.path.join(GOLDEN, "single_prims.npz"))
+    k = S.KIND_NAMES[kind].lower()
+    for t in range(len(g[k + "_params"])):
+        prim = S.new_prims(1)
+        prim["kind"] = kind
+        prim["q"][0] = g[k + "_params"][t]
+        got = np.asarray(capi.prim_aabb(prim[0])).reshape(-1)
+        want = np.asarray(g[k + "_aabb"][t], dtype=np.float64).reshape(-1)
+        assert np.array_equal(got.view(np.int64), want.view(np.int64)), (k, t)

@@ -1,0 +1,73 @@
+"""The multi-rank path on CPU: world_size 2 and 3 over gloo.  Every rank packs its share of a known frame exactly as
+rt_render_tiles lays it out, the tiles are gathered to rank 0 through the same TileGather bench.py uses over RCCL,
+and rank 0 reassembles the frame.  Also checks that the library's tile arithmetic agrees with the host restatement."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd import capi, tiles
+
+
+def known_frame(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    return np.stack([(x * 7 + y * 3) % 251, (x ^ y) % 256, (x * y + 11) % 253], axis=-1).astype(np.uint8)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def worker(rank, world, port, w, h, tile, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frame = known_frame(w, h)
+        tg = tiles.TileGather(torch, dist, w, h, tile, world, rank, "cpu")
+        for step in range(2):                       # buffers are reused frame after frame
+            tg.local.copy_(torch.from_numpy(tiles.pack_rank_tiles((frame + step).astype(np.uint8), tile, world, rank)))
+            dist.barrier()
+            gathered = tg.gather()
+            if rank == 0:
+                got = tiles.assemble(gathered.numpy(), w, h, tile, world)
+                assert np.array_equal(got, (frame + step).astype(np.uint8))
+        # the timing reduction of bench.py: MAX over ranks
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+        if rank == 0:
+            open(out_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,tile", [(2, 200, 120, 32), (3, 97, 65, 16), (2, 64, 64, 64)])
+def test_tiles_gather_over_gloo(tmp_path, world, w, h, tile):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(worker, args=(world, free_port(), w, h, tile, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+@pytest.mark.parametrize("w,h,tile,n", [(3840, 2160, 64, 8), (200, 120, 32, 2), (97, 65, 16, 3), (64, 64, 64, 2), (17, 5, 16, 4)])
+def test_library_tile_arithmetic_matches(w, h, tile, n):
+    t = capi.Tiling(w, h, tile, n)
+    assert capi.tile_count(t) == tiles.tile_count(w, h, tile)
+    assert capi.tiles_per_rank(t) == tiles.tiles_per_rank(w, h, tile, n)
+    owned = [tiles.rank_tiles(w, h, tile, n, r) for r in range(n)]
+    assert sorted(sum(owned, [])) == list(range(tiles.tile_count(w, h, tile)))       # a partition: every tile exactly once
+    assert max(map(len, owned)) - min(map(len, owned)) <= 1                          # balanced to within one tile
+
+
+def test_pack_then_assemble_is_identity():
+    for w, h, tile, n in [(50, 30, 16, 3), (64, 48, 16, 1), (33, 33, 32, 5)]:
+        frame = known_frame(w, h)
+        gathered = np.concatenate([tiles.pack_rank_tiles(frame, tile, n, r) for r in range(n)])
+        assert np.array_equal(tiles.assemble(gathered, w, h, tile, n), frame)
