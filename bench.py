@@ -186,6 +186,14 @@ def main():
 
     if rank == 0:
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        # HBM-side bytes per launch of the same kernel on the same workload, from committed rocprofv3 PMC passes
+        # (profiles/make_traffic.py); null when no measurement matches this run
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+        if world == 1 and args.max_scatters == 0 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj["workload"]["n_side"] == args.n_side and tj["workload"]["rays_per_frame"] == rays_per_frame:
+                traffic = tj["traffic_bytes_per_launch"]
         frame_bytes = bytes_primary + bytes_shadow
         device_ms = sum(stage_ms.values())
         out = {
@@ -211,7 +219,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,
                 "algorithmic_bytes_per_launch": k_bytes,
                 "stage_ms_per_frame": stage_ms,

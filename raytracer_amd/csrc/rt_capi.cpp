@@ -25,7 +25,7 @@ int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
             return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
-constexpr uint32_t kQueueSlots = 64;
+constexpr uint32_t kQueueSlots = 64 * RT_QUEUE_PARTS;   // RT_QUEUE_PARTS heads per persistent launch
 constexpr size_t kCounterBytes = static_cast<size_t>(RT_CTR_SHARDS) * RT_CTR_STRIDE * sizeof(uint64_t);
 static_assert(sizeof(rt_counters) == 8 * sizeof(uint64_t), "counter block");
 
@@ -410,7 +410,8 @@ int next_queue(rt_ctx* ctx, unsigned int** q) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, kQueueSlots * sizeof(unsigned int), ctx->stream));
         ctx->queue_used = 0;
     }
-    *q = ctx->d_queue + ctx->queue_used++;
+    *q = ctx->d_queue + ctx->queue_used;
+    ctx->queue_used += RT_QUEUE_PARTS;
     return RT_OK;
 }
 

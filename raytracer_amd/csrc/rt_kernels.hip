@@ -658,6 +658,10 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     uint32_t n_cast = 0, n_hit = 0;
     uint32_t q_next = 0, q_end = 0;          // wave-uniform: the unread part of the current chunk
     bool q_empty = false;
+    // The chunk sequence is cut into RT_QUEUE_PARTS contiguous runs, one per XCD (workgroups go round-robin over the
+    // XCDs): the waves behind one L2 work through neighbouring rays.  A wave whose run is used up helps with the others.
+    const uint32_t n_chunks = static_cast<uint32_t>((static_cast<unsigned long long>(n_rays) + RT_CHUNK - 1) / RT_CHUNK);
+    uint32_t q_part = blockIdx.x % RT_QUEUE_PARTS, q_tried = 0;
 
     for (;;) {
         const int n_trav = __popcll(__ballot(state == TRAV));
@@ -701,12 +705,19 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 const unsigned long long idle = __ballot(state == IDLE);
                 if (!idle) break;
                 if (q_next == q_end) {
-                    unsigned int c = 0;
-                    if (lane == 0) c = atomicAdd(queue, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
-                    const unsigned long long first = static_cast<unsigned long long>(c) * RT_CHUNK;
-                    if (first >= n_rays) { q_empty = true; break; }
-                    q_next = static_cast<uint32_t>(first);
+                    bool got = false;
+                    uint32_t chunk = 0;
+                    while (q_tried < RT_QUEUE_PARTS) {
+                        const uint32_t p0 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * q_part / RT_QUEUE_PARTS);
+                        const uint32_t p1 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * (q_part + 1) / RT_QUEUE_PARTS);
+                        unsigned int c = 0;
+                        if (lane == 0) c = atomicAdd(queue + q_part, 1u);
+                        c = __builtin_amdgcn_readfirstlane(c);
+                        if (c < p1 - p0) { chunk = p0 + c; got = true; break; }
+                        q_part = (q_part + 1) % RT_QUEUE_PARTS; ++q_tried;
+                    }
+                    if (!got) { q_empty = true; break; }
+                    q_next = chunk * RT_CHUNK;
                     q_end = (n_rays - q_next < RT_CHUNK) ? n_rays : q_next + RT_CHUNK;
                 }
                 const uint32_t avail = q_end - q_next, n_idle = static_cast<uint32_t>(__popcll(idle));
