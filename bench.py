@@ -172,12 +172,9 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = ctx.timing()
     ctx.set_timing(False)
-    if args.max_scatters > 0:
-        kname, k_ms, k_bytes = "k_render_bounce<false>", tm["bounce_ms"] / max(tm["bounce_launches"], 1), bytes_primary + bytes_shadow
-    else:
-        # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights
-        kname, k_ms, k_bytes = "k_rays<1,false,false> (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
-            bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
+    # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights and per bounce level
+    kname, k_ms, k_bytes = "k_rays<1,false,0> (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
+        bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
     stage_ms = {k: tm[k] / args.steps for k in ("primary_ms", "shadow_ms", "resolve_ms", "bounce_ms")}
     t = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cuda")
     if dist is not None:

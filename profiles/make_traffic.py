@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNEL = "k_rays<1, false, false>"
+KERNEL = "k_rays<1, false, 0>"
 
 
 def mean_counter(path, counter):

@@ -70,8 +70,8 @@ struct rt_ctx {
         if (hipEvent_t e = timing_event(2 * ev_kind.size() - 1)) (void)hipEventRecord(e, stream);
     }
     // grow-only scratch of the *_host conveniences
-    void* scratch[6] = {};    // 0..2 host conveniences, 3 frame working set, 4 one sample's colours, 5 sample sums
-    size_t scratch_bytes[6] = {};
+    void* scratch[7] = {};    // 0..2 host conveniences, 3 frame working set, 4 one sample's colours, 5 sample sums, 6 bounce levels
+    size_t scratch_bytes[7] = {};
 
     void free_scene() {
         if (d_nodes) (void)hipFree(d_nodes);
@@ -429,6 +429,59 @@ int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
     fb.lighting = d + 6*n; fb.contrib = d + 7*n;
     fb.id = reinterpret_cast<int32_t*>(d + planes * n);
     fb.n = n;
+    fb.ray = nullptr; fb.rawn = nullptr; fb.alive = nullptr; fb.level = 0;
+    return RT_OK;
+}
+
+// The same frame as a chain of levels: level 0 from the camera, level k + 1 along the mirror directions of level k
+// (RayTracer::trace_ray_recursive, raytracer.cpp:281-371).  Every level runs the primary / shadow kernels of the plain
+// frame; a resolve kernel closes the level and leaves the next level's rays, a fold kernel blends the levels at the end.
+int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out, int max_scatters,
+                        double min_scatter_intensity, uint8_t* rgb_dev, int32_t* hit_id_dev) {
+    const uint32_t n_lights = ctx->sc.n_lights;
+    const uint32_t batch = n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH;
+    FrameBufs fb;
+    if (int rc = frame_bufs(ctx, n_out, batch, fb)) return rc;
+    const size_t levels = static_cast<size_t>(max_scatters) + 1;
+    // 9 more double planes (ray, raw normal), Fresnel weights, then the 32-bit and 8-bit planes
+    const size_t bytes = n_out * (9 * sizeof(double) + max_scatters * sizeof(double) + levels * sizeof(uint32_t)
+                                  + max_scatters * sizeof(uint32_t) + 2) + 256;
+    void* base = nullptr;
+    if (int rc = ctx->need(6, bytes, &base)) return rc;
+    double* d = static_cast<double*>(base);
+    fb.ray = d; fb.rawn = d + 6 * n_out;
+    LevelBufs lv;
+    lv.fr = d + 9 * n_out;
+    lv.local = reinterpret_cast<uint32_t*>(d + (9 + static_cast<size_t>(max_scatters)) * n_out);
+    lv.tint = lv.local + levels * n_out;
+    lv.last = reinterpret_cast<uint8_t*>(lv.tint + static_cast<size_t>(max_scatters) * n_out);
+    fb.alive = lv.last + n_out;
+    if (pm.mode == 1) RT_HIP(hipMemsetAsync(fb.id, 0xFF, n_out * sizeof(int32_t), ctx->stream));
+    ctx->queue_used = kQueueSlots;
+    for (int level = 0; level <= max_scatters; ++level) {
+        fb.level = level;
+        unsigned int* q = nullptr;
+        if (int rc = next_queue(ctx, &q)) return rc;
+        ctx->mark_begin(0);
+        RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting,
+                                 level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill_min));
+        ctx->mark_end();
+        for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
+            const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
+            if (int rc = next_queue(ctx, &q)) return rc;
+            ctx->mark_begin(1);
+            RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
+                                    ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
+            ctx->mark_end();
+            ctx->mark_begin(2);
+            RT_HIP(rt_launch_bounce_resolve(ctx->stream, &ctx->sc, &fb, &lv, nb, l0 == 0, l0 + nb >= n_lights, max_scatters,
+                                            min_scatter_intensity));
+            ctx->mark_end();
+        }
+    }
+    ctx->mark_begin(3);
+    RT_HIP(rt_launch_bounce_fold(ctx->stream, &ctx->sc, &lv, n_out, rgb_dev));
+    ctx->mark_end();
     return RT_OK;
 }
 
@@ -576,13 +629,7 @@ int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatter
         }
         return RT_OK;
     }
-    if (max_scatters > 0) {
-        ctx->mark_begin(3);
-        RT_HIP(rt_launch_render_bounce(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, max_scatters, min_scatter_intensity,
-                                       rgb_dev, hit_id_dev, ctx->d_ctr));
-        ctx->mark_end();
-        return RT_OK;
-    }
+    if (max_scatters > 0) return run_bounce_pipeline(ctx, dc, pm, nw, n_out, max_scatters, min_scatter_intensity, rgb_dev, hit_id_dev);
     return run_pipeline(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev);
 }
 
@@ -618,14 +665,11 @@ int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int ran
     if (nw64 * 64u * RT_LIGHT_BATCH >= 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "too many tiles for one launch");
     const uint32_t nw = static_cast<uint32_t>(nw64);
     DevCamera dc; to_dev_camera(*cam, dc);
-    if (ctx->sc.n_lights == 0 || max_scatters > 0) {
-        // padding of edge tiles and of a short last round stays zero
+    if (ctx->sc.n_lights == 0) {
         RT_HIP(hipMemsetAsync(rgb_dev, 0, n_out * 3, ctx->stream));
-        if (ctx->sc.n_lights == 0) return RT_OK;
-        RT_HIP(rt_launch_render_bounce(ctx->stream, &ctx->sc, &dc, &pm, nw, ctx->counting, max_scatters, min_scatter_intensity,
-                                       rgb_dev, nullptr, ctx->d_ctr));
         return RT_OK;
     }
+    if (max_scatters > 0) return run_bounce_pipeline(ctx, dc, pm, nw, n_out, max_scatters, min_scatter_intensity, rgb_dev, nullptr);
     return run_pipeline(ctx, dc, pm, nw, n_out, rgb_dev, nullptr);
 }
 

@@ -53,6 +53,19 @@ struct FrameBufs {
     double *contrib;               // [light in batch][n] this light's term
     int32_t *id;                   // primary hit id, -1 = miss / padding
     size_t n;
+    // Mirror-bounce frames only (null otherwise): the chain of trace_ray_recursive is walked level by level.
+    double *ray;                   // 6 planes: origin xyz, direction xyz of the ray traced at this level
+    double *rawn;                  // 3 planes: the intersector's normal as it left the primitive test
+    uint8_t *alive;                // levels >= 1: this slot still carries a ray
+    int level;
+};
+
+// Per-level results of a mirror-bounce frame, folded into the final colour at the end.
+struct LevelBufs {
+    uint32_t *local;               // [level][n] local colour, r | g << 8 | b << 16 (linear 8 bit)
+    double   *fr;                  // [level][n] Fresnel weight of the bounce leaving this level
+    uint32_t *tint;                // [level][n] albedo | metallic flag << 24
+    uint8_t  *last;                // [n] deepest level reached
 };
 
 extern "C" {
@@ -72,8 +85,9 @@ hipError_t rt_launch_finish_samples(hipStream_t st, const uint32_t* acc, size_t 
 hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec* rec, const double* rays, uint64_t n, double* records);
 hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
                                 uint8_t* rgb, rt_counters* ctr);
-hipError_t rt_launch_render_bounce(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_waves,
-                                   int counting, int max_scatters, double min_si, uint8_t* rgb, int32_t* ids, rt_counters* ctr);
+hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, const LevelBufs* lv, uint32_t n_batch,
+                                    int first, int last, int max_scatters, double min_si);
+hipError_t rt_launch_bounce_fold(hipStream_t st, const DevScene* sc, const LevelBufs* lv, size_t n, uint8_t* rgb);
 hipError_t rt_launch_assemble(hipStream_t st, int width, int height, int tile, int tiles_x, int n_ranks, int tiles_per_rank,
                               const uint8_t* gathered, uint8_t* frame);
 }

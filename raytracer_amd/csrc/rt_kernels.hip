@@ -641,11 +641,13 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 // take the next rays of the wave's current chunk (chunks of RT_CHUNK consecutive rays are handed out by one atomic
 // counter), then the wave advances all its walks by one while-while round.  Finished lanes are only swapped once
 // RT_REFILL_MIN of them have piled up, so that the result / set-up code also runs on a well-filled wave.
-// MODE 0 - primary rays: ray i = lane (i % 64) of tile (i / 64) of the pixel map; writes ids / dist (optional) and,
-//          with RECORD, the surface record (point, re-normalised normal, id) the shadow pass starts from.
+// MODE 0 - closest hits: ray i = lane (i % 64) of tile (i / 64) of the pixel map; writes ids / dist (optional) and,
+//          with RECORD >= 1, the surface record (point, re-normalised normal, id) the shadow pass starts from.
+//          RECORD == 2 is a level of a mirror-bounce frame: level 0 also stores its camera rays, deeper levels take
+//          their rays from the slots (left there by k_bounce_resolve), and the raw normal is kept for the Fresnel term.
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
-template <int MODE, bool COUNT, bool RECORD>
+template <int MODE, bool COUNT, int RECORD>
 __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
@@ -685,6 +687,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                             double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
                             fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
                             fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
+                            if (RECORD == 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
                         }
                     }
                 } else {
@@ -693,8 +696,11 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     if (!w.blocked()) {
                         const rt_light L = sc.lights[light0 + lj];
                         const rt_mat_rec m = sc.mats[fb.id[out]];
+                        // the view vector points at the origin of the ray that found this surface (raytracer.cpp:185-186)
+                        double vox = cam.pos[0], voy = cam.pos[1], voz = cam.pos[2];
+                        if (fb.ray && fb.level > 0) { vox = fb.ray[out]; voy = fb.ray[fb.n + out]; voz = fb.ray[2*fb.n + out]; }
                         c = light_value(L, m, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out],
-                                        w.r.dx, w.r.dy, w.r.dz, cam.pos[0], cam.pos[1], cam.pos[2]);
+                                        w.r.dx, w.r.dy, w.r.dz, vox, voy, voz);
                     }
                     fb.contrib[static_cast<size_t>(lj) * fb.n + out] = c;
                 }
@@ -731,10 +737,27 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     if (p.valid) {
                         out = p.out;
                         if (MODE == 0) {
-                            RayD r; primary_ray(cam, p.x, p.y, r);
-                            w.start(sc, r, my_stack, deep.e, 0.0);
-                            ++n_cast;
-                            state = w.done() ? DONE : TRAV;
+                            RayD r;
+                            bool have = true;
+                            if (RECORD == 2 && fb.level > 0) {
+                                // a bounce level: the ray was left in the slot by the level above
+                                if (fb.alive[out]) {
+                                    r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
+                                    r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
+                                    r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
+                                } else { have = false; fb.id[out] = -1; }
+                            } else {
+                                primary_ray(cam, p.x, p.y, r);
+                                if (RECORD == 2) {
+                                    fb.ray[out] = r.ox; fb.ray[fb.n + out] = r.oy; fb.ray[2*fb.n + out] = r.oz;
+                                    fb.ray[3*fb.n + out] = r.dx; fb.ray[4*fb.n + out] = r.dy; fb.ray[5*fb.n + out] = r.dz;
+                                }
+                            }
+                            if (have) {
+                                w.start(sc, r, my_stack, deep.e, 0.0);
+                                ++n_cast;
+                                state = w.done() ? DONE : TRAV;
+                            }
                         } else if (fb.id[out] >= 0) {
                             const rt_light L = sc.lights[light0 + g / n_tiles];
                             RayD r;
@@ -759,8 +782,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     }
     const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
     if (MODE == 0) {
-        add_counter(ctr, shard, F_PRIMARY, n_cast);
-        add_counter(ctr, shard, F_HITS, n_hit);
+        const bool bounce_level = RECORD == 2 && fb.level > 0;
+        add_counter(ctr, shard, bounce_level ? F_BOUNCE : F_PRIMARY, n_cast);
+        add_counter(ctr, shard, F_HITS, bounce_level ? 0u : n_hit);
         if (COUNT) { add_counter(ctr, shard, F_VN_P, w.vn); add_counter(ctr, shard, F_VP_P, w.vp); }
     } else {
         add_counter(ctr, shard, F_SHADOW, n_cast);
@@ -881,88 +905,83 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
     add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, F_SHADOW, sctr.shadow_rays);
 }
 
-// The whole pixel pipeline of render_unaccelerated_ppm in one lane (raytracer.cpp:401-438), used when mirror
-// bounces are on: trace_ray_recursive (raytracer.cpp:281-371) unrolled into a loop - walk down the mirror chain
-// keeping each level's local colour, Fresnel weight and tint, then fold the 8-bit blends back up.
-template <bool COUNT>
-__global__ void __launch_bounds__(64) k_render_bounce(DevScene sc, DevCamera cam, PixelMap pm, int max_scatters,
-                                                      double min_scatter_intensity, uint8_t* __restrict__ rgb,
-                                                      int32_t* __restrict__ ids, rt_counters* ctr) {
-    uint2* my_stack = nullptr;
-    const uint32_t w = xcd_contiguous(blockIdx.x, gridDim.x);
-    const Pixel p = map_pixel(pm, w, threadIdx.x & 63u);
-    ShadeCounters sctr = { 0, 0, 0 };
-    uint32_t vn = 0, vp = 0, bounce_rays = 0;
-    bool primary_hit = false;
-    if (p.valid) {
-        RayD r; primary_ray(cam, p.x, p.y, r);
-        double   lvl_fr[RT_MAX_SCATTERS];
-        uint32_t lvl_local[RT_MAX_SCATTERS + 1];
-        uint32_t lvl_tint[RT_MAX_SCATTERS];      // albedo | metallic flag << 24
-        int last = 0;
-        for (int depth = 0; ; ++depth) {
-            Best b;
-            const bool hit = traverse<0, COUNT>(sc, r, my_stack, 0.0, b, vn, vp);
-            if (depth == 0) { if (ids) ids[p.out] = b.id; primary_hit = hit; }
-            uint32_t local = 0;
-            HitD h;
-            if (hit) {
-                const rt_prim_rec* rec = sc.recs + b.slot;
-                hit_record<true>(rec, rec->kind, r, h);
-                local = shade<COUNT>(sc, h, b.id, r.ox, r.oy, r.oz, my_stack, sctr);
-            }
-            lvl_local[depth] = local; last = depth;
-            if (depth >= max_scatters || !hit) break;
+// Mirror bounces (trace_ray_recursive, raytracer.cpp:281-371) as a level-by-level pipeline: each level is traced and
+// shadow-tested by the same ray kernels as a plain frame; this kernel closes a level - local colour, Fresnel weight,
+// tint, and the ray of the next level - and k_bounce_fold blends the levels back up once the chain has ended.
+__global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, FrameBufs fb, LevelBufs lv, uint32_t n_batch, int first, int last,
+                                                        int max_scatters, double min_scatter_intensity) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= fb.n) return;
+    const int level = fb.level;
+    if (level > 0 && !fb.alive[i]) return;
+    const int32_t id = fb.id[i];
+    uint32_t local = 0;
+    if (id >= 0) {
+        double lighting = first ? 0.0 : fb.lighting[i];
+        for (uint32_t j = 0; j < n_batch; ++j) lighting += fb.contrib[static_cast<size_t>(j) * fb.n + i];
+        if (!last) { fb.lighting[i] = lighting; return; }
+        local = finish_shade(sc.mats[id], lighting);
+    } else if (!last) return;
+    lv.local[static_cast<size_t>(level) * fb.n + i] = local;
+    lv.last[i] = static_cast<uint8_t>(level);
+    bool go = false;
+    if (id >= 0 && level < max_scatters) {
+        const rt_mat_rec m = sc.mats[id];
+        const double dx = fb.ray[3*fb.n + i], dy = fb.ray[4*fb.n + i], dz = fb.ray[5*fb.n + i];
+        const double nx = fb.rawn[i], ny = fb.rawn[fb.n + i], nz = fb.rawn[2*fb.n + i];
+        const double dlen = dsqrt(dx*dx + dy*dy + dz*dz);
+        const double inv_len = (dlen > 1e-15) ? (1.0 / dlen) : 1.0;
+        const double vx = -dx * inv_len, vy = -dy * inv_len, vz = -dz * inv_len;
+        const double ct = nx*vx + ny*vy + nz*vz;
+        const double cos_theta = (0.0 < ct) ? ct : 0.0;
+        double f0;
+        if (m.metallic <= 0.0) { const double r0 = (m.ior - 1.0) / (m.ior + 1.0); f0 = clampd(r0 * r0, 0.0, 1.0); }
+        else {
+            const double avg = (static_cast<double>(m.albedo[0]) + static_cast<double>(m.albedo[1]) + static_cast<double>(m.albedo[2])) / (3.0 * 255.0);
+            f0 = clampd(avg, 0.0, 1.0);
+        }
+        const double fr = f0 + (1.0 - f0) * pow(1.0 - cos_theta, 5.0);
+        if (!(fr <= 0.0 || fr < min_scatter_intensity)) {
+            go = true;
+            lv.fr[static_cast<size_t>(level) * fb.n + i] = fr;
+            lv.tint[static_cast<size_t>(level) * fb.n + i] = static_cast<uint32_t>(m.albedo[0]) | static_cast<uint32_t>(m.albedo[1]) << 8
+                                                           | static_cast<uint32_t>(m.albedo[2]) << 16 | (m.metallic > 0.0 ? 1u << 24 : 0u);
+            // mirror direction exactly as the intersectors leave it in the Hit (mesh.cpp:236-247 and siblings)
+            const double ddn = dx*nx + dy*ny + dz*nz;
+            const double tx = dx - 2.0 * ddn * nx, ty = dy - 2.0 * ddn * ny, tz = dz - 2.0 * ddn * nz;
+            double len = dsqrt(tx*tx + ty*ty + tz*tz);
+            if (len < 1e-15) len = 1.0;
+            const double rx = tx/len, ry = ty/len, rz = tz/len;
+            const double eps = 1e-6;                                        // raytracer.cpp:332-336
+            fb.ray[i] = fb.px[i] + rx * eps; fb.ray[fb.n + i] = fb.py[i] + ry * eps; fb.ray[2*fb.n + i] = fb.pz[i] + rz * eps;
+            fb.ray[3*fb.n + i] = rx; fb.ray[4*fb.n + i] = ry; fb.ray[5*fb.n + i] = rz;
+        }
+    }
+    fb.alive[i] = go ? 1 : 0;
+}
 
-            const rt_mat_rec m = sc.mats[b.id];
-            const double inv_len = (r.dlen > 1e-15) ? (1.0 / r.dlen) : 1.0;
-            const double vx = -r.dx * inv_len, vy = -r.dy * inv_len, vz = -r.dz * inv_len;
-            const double ct = h.nx*vx + h.ny*vy + h.nz*vz;
-            const double cos_theta = (0.0 < ct) ? ct : 0.0;
-            double f0;
-            if (m.metallic <= 0.0) { const double r0 = (m.ior - 1.0) / (m.ior + 1.0); f0 = clampd(r0 * r0, 0.0, 1.0); }
-            else {
-                const double avg = (static_cast<double>(m.albedo[0]) + static_cast<double>(m.albedo[1]) + static_cast<double>(m.albedo[2])) / (3.0 * 255.0);
-                f0 = clampd(avg, 0.0, 1.0);
-            }
-            const double fr = f0 + (1.0 - f0) * pow(1.0 - cos_theta, 5.0);
-            if (fr <= 0.0 || fr < min_scatter_intensity) break;
-            lvl_fr[depth] = fr;
-            lvl_tint[depth] = static_cast<uint32_t>(m.albedo[0]) | static_cast<uint32_t>(m.albedo[1]) << 8
-                            | static_cast<uint32_t>(m.albedo[2]) << 16 | (m.metallic > 0.0 ? 1u << 24 : 0u);
-            const double eps = 1e-6;
-            RayD nr;
-            nr.ox = h.px + h.rx * eps; nr.oy = h.py + h.ry * eps; nr.oz = h.pz + h.rz * eps;
-            nr.dx = h.rx; nr.dy = h.ry; nr.dz = h.rz;
-            nr.dlen = dsqrt(nr.dx*nr.dx + nr.dy*nr.dy + nr.dz*nr.dz);
-            r = nr; ++bounce_rays;
-        }
-        uint32_t colour = lvl_local[last];
-        for (int k = last - 1; k >= 0; --k) {
-            const uint32_t tint = lvl_tint[k];
-            uint32_t out = 0;
+// Fold the 8-bit blends back up the chain (raytracer.cpp:342-370), then the display transfer.
+__global__ void __launch_bounds__(256) k_bounce_fold(DevScene sc, LevelBufs lv, size_t n, uint8_t* __restrict__ rgb) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int last = lv.last[i];
+    uint32_t colour = lv.local[static_cast<size_t>(last) * n + i];
+    for (int k = last - 1; k >= 0; --k) {
+        const uint32_t tint = lv.tint[static_cast<size_t>(k) * n + i];
+        const uint32_t loc_k = lv.local[static_cast<size_t>(k) * n + i];
+        const double fr = lv.fr[static_cast<size_t>(k) * n + i];
+        uint32_t out = 0;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const double sec = static_cast<double>((colour >> (8*ch)) & 255u);
-                double tinted = sec;
-                if (tint >> 24) tinted = static_cast<double>(round_u8((static_cast<double>((tint >> (8*ch)) & 255u) / 255.0) * sec));
-                const double loc = static_cast<double>((lvl_local[k] >> (8*ch)) & 255u);
-                out |= round_u8((1.0 - lvl_fr[k]) * loc + lvl_fr[k] * tinted) << (8*ch);
-            }
-            colour = out;
+        for (int ch = 0; ch < 3; ++ch) {
+            const double sec = static_cast<double>((colour >> (8*ch)) & 255u);
+            double tinted = sec;
+            if (tint >> 24) tinted = static_cast<double>(round_u8((static_cast<double>((tint >> (8*ch)) & 255u) / 255.0) * sec));
+            const double loc = static_cast<double>((loc_k >> (8*ch)) & 255u);
+            out |= round_u8((1.0 - fr) * loc + fr * tinted) << (8*ch);
         }
-        uint8_t* px = rgb + static_cast<size_t>(p.out) * 3;
-        px[0] = sc.gamma[colour & 255u]; px[1] = sc.gamma[(colour >> 8) & 255u]; px[2] = sc.gamma[(colour >> 16) & 255u];
+        colour = out;
     }
-    const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
-    add_counter(ctr, shard, F_PRIMARY, p.valid ? 1 : 0);
-    add_counter(ctr, shard, F_HITS, primary_hit ? 1 : 0);
-    add_counter(ctr, shard, F_SHADOW, sctr.shadow_rays);
-    add_counter(ctr, shard, F_BOUNCE, bounce_rays);
-    if (COUNT) {
-        add_counter(ctr, shard, F_VN_P, vn); add_counter(ctr, shard, F_VP_P, vp);
-        add_counter(ctr, shard, F_VN_S, sctr.vn); add_counter(ctr, shard, F_VP_S, sctr.vp);
-    }
+    rgb[i*3] = sc.gamma[colour & 255u]; rgb[i*3 + 1] = sc.gamma[(colour >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(colour >> 16) & 255u];
 }
 
 // Scatter gathered per-rank tile buffers into a row-major frame (one thread per pixel).
@@ -1010,12 +1029,16 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
                                         const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const FrameBufs none{};
     const uint32_t n_rays = n_tiles * 64u;
-    if (fb) {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
+    const dim3 grid(n_waves), block(64);
+    if (fb && fb->ray) {
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, 2>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<0, false, 2>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
+    } else if (fb) {
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, 1>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<0, false, 1>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
     } else {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<0, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, 0>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<0, false, 0>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
     }
     return hipGetLastError();
 }
@@ -1024,8 +1047,8 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
                                        uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                                        const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t n_rays = n_tiles * n_batch * 64u;
-    if (counting) hipLaunchKernelGGL((k_rays<1, true, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
-    else          hipLaunchKernelGGL((k_rays<1, false, false>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+    if (counting) hipLaunchKernelGGL((k_rays<1, true, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+    else          hipLaunchKernelGGL((k_rays<1, false, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
     return hipGetLastError();
 }
 
@@ -1063,10 +1086,16 @@ extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, c
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_render_bounce(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_waves,
-                                              int counting, int max_scatters, double min_si, uint8_t* rgb, int32_t* ids, rt_counters* ctr) {
-    if (counting) hipLaunchKernelGGL(k_render_bounce<true>, dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, max_scatters, min_si, rgb, ids, ctr);
-    else          hipLaunchKernelGGL(k_render_bounce<false>, dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, max_scatters, min_si, rgb, ids, ctr);
+extern "C" hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, const LevelBufs* lv, uint32_t n_batch,
+                                               int first, int last, int max_scatters, double min_si) {
+    const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
+    if (nb) hipLaunchKernelGGL(k_bounce_resolve, dim3(nb), dim3(256), 0, st, *sc, *fb, *lv, n_batch, first, last, max_scatters, min_si);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_bounce_fold(hipStream_t st, const DevScene* sc, const LevelBufs* lv, size_t n, uint8_t* rgb) {
+    const uint32_t nb = static_cast<uint32_t>((n + 255) / 256);
+    if (nb) hipLaunchKernelGGL(k_bounce_fold, dim3(nb), dim3(256), 0, st, *sc, *lv, n, rgb);
     return hipGetLastError();
 }
 
