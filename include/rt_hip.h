@@ -117,6 +117,17 @@ int rt_scene_load_json(const char* path, const rt_build_opts* opts_or_null, rt_s
 /* The same from text already in memory (the per-class readers Cube/Plane/Cylinder/Sphere::read_from_json,
  * mesh.cpp:52,316,544,707, take text blocks rather than paths). */
 int rt_scene_load_json_text(const char* text, uint64_t len, const rt_build_opts* opts_or_null, rt_scene** out);
+/* Albedo textures (Mesh::setAlbedoTexture, mesh.h:47; sampled by Mesh::evaluate_albedo, mesh.cpp:21-45: wrap, nearest,
+ * x = floor(u * (w - 1))).  rt_scene_load_json reads the files named by "albedo_texture_ppm" itself and, like the
+ * reference (mesh.cpp:105-110), keeps the solid colour when a file does not load.  For scenes built in memory:
+ * prim_texture[i] = index into textures, or -1; call before rt_scene_upload.  Pixels are copied. */
+typedef struct rt_texture { int32_t width, height; const uint8_t* rgb; } rt_texture;   /* rows top to bottom, 3 bytes per pixel */
+int rt_scene_set_textures(rt_scene* scene, const rt_texture* textures, uint32_t n_textures, const int32_t* prim_texture);
+/* Borrowed view of the texture of one primitive (width 0 when it has none). */
+int rt_scene_get_texture(const rt_scene* scene, uint64_t prim_id, rt_texture* out);
+/* Image::loadFromFile (utils.cpp:212-250): P3 / P6, maxval <= 255, samples as stored.  With rgb_or_null == NULL only the
+ * header is returned.  RT_ERR_IO: cannot open; RT_ERR_PARSE: not a PPM this reader accepts. */
+int rt_image_read_ppm(const char* path, int32_t* width, int32_t* height, int32_t* maxval, uint8_t* rgb_or_null, uint64_t capacity);
 int rt_scene_destroy(rt_scene* scene);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* Borrowed views, valid until rt_scene_destroy. */
@@ -162,11 +173,11 @@ int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb
  * [6..8] surface normal, [9..11] reflected direction, [12..13] surface u, v (mesh.cpp:262-278, 497-512, 669-679, 918;
  * triangles: barycentric edge coordinates), [14..15] zero. */
 int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double* records16_dev);
-/* RayTracer::shade (raytracer.h:34, raytracer.cpp:159-279) for caller-supplied hits: 8 doubles each ([0..2] point,
- * [3..5] normal, [6] primitive id, [7] unused; id -2 = a hit that names no primitive, shaded white with the default
- * material as the reference does; any other id outside the scene = black) and the origin of the ray that
- * produced each hit (3 doubles).  Linear 8-bit colour. */
-int rt_shade_hits(rt_ctx* ctx, const double* hits8_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev);
+/* RayTracer::shade (raytracer.h:34, raytracer.cpp:159-279) for caller-supplied hits: 10 doubles each ([0..2] point,
+ * [3..5] normal, [6] primitive id, [7..8] surface u, v, [9] non-zero when u, v are set; id -2 = a hit that names no
+ * primitive, shaded white with the default material as the reference does; any other id outside the scene = black)
+ * and the origin of the ray that produced each hit (3 doubles).  Linear 8-bit colour. */
+int rt_shade_hits(rt_ctx* ctx, const double* hits10_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev);
 /* RayTracer::render_unaccelerated_ppm's pixel loop with samples_per_pixel = 1 (raytracer.cpp:401-438):
  * trace, shade with hard shadows, up to max_scatters mirror bounces (<= 8), gamma.  rgb_dev is
  * rect.w * rect.h * 3 bytes; hit_id_dev (may be NULL) receives the primary hit ids. */
@@ -205,7 +216,7 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* cam, int max_scatters, do
 int rt_trace_primary_host(rt_ctx* ctx, const rt_camera* cam, int32_t* hit_id_host, double* dist_host);
 int rt_trace_rays_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, int32_t* hit_id_host, double* dist_host);
 int rt_trace_rays_full_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, double* records16_host);
-int rt_shade_hits_host(rt_ctx* ctx, const double* hits8_host, const double* view3_host, uint64_t n, uint8_t* rgb_host);
+int rt_shade_hits_host(rt_ctx* ctx, const double* hits10_host, const double* view3_host, uint64_t n, uint8_t* rgb_host);
 /* Cube/Plane/Cylinder/Sphere::intersect (mesh.cpp:159,371,597,795) of ONE primitive, outside any scene, for n rays;
  * records as rt_trace_rays_full with id 0 on a hit.  Needs no uploaded scene. */
 int rt_intersect_prim_host(rt_ctx* ctx, const rt_prim_desc* prim, const double* rays6_host, uint64_t n, double* records16_host);

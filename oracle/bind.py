@@ -42,8 +42,13 @@ class Bvh(C.Structure):
                 ("n_loose", C.c_int64), ("radius", C.c_float)]
 
 
+class _Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.c_void_p)]
+
+
 class _Scene(C.Structure):
-    _fields_ = [("prims", C.c_void_p), ("n_prims", C.c_int64), ("lights", C.c_void_p), ("n_lights", C.c_int64)]
+    _fields_ = [("prims", C.c_void_p), ("n_prims", C.c_int64), ("lights", C.c_void_p), ("n_lights", C.c_int64),
+                ("textures", C.c_void_p), ("n_textures", C.c_int64), ("prim_tex", C.c_void_p)]
 
 
 def new_prims(n):
@@ -92,11 +97,19 @@ class Oracle:
 
     # -- helpers -------------------------------------------------------------------------------
     @staticmethod
-    def scene(prims, lights=None):
+    def scene(prims, lights=None, textures=None, prim_tex=None):
+        """textures: list of (h, w, 3) uint8 arrays; prim_tex: texture index per primitive (-1 = none)."""
         prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, LIGHT_DT), dtype=LIGHT_DT)
-        s = _Scene(_ptr(prims), len(prims), _ptr(lights), len(lights))
+        s = _Scene(_ptr(prims), len(prims), _ptr(lights), len(lights), None, 0, None)
         s._keep = (prims, lights)
+        if textures:
+            arrs = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
+            table = (_Texture * len(arrs))(*[_Texture(a.shape[1], a.shape[0], a.ctypes.data) for a in arrs])
+            pt = np.ascontiguousarray(prim_tex, dtype=np.int32)
+            assert len(pt) == len(prims)
+            s.textures, s.n_textures, s.prim_tex = C.cast(table, C.c_void_p), len(arrs), _ptr(pt)
+            s._keep += (arrs, table, pt)
         return s
 
     def camera(self, pos, direction, up=None, focal=35.0, sensor=(36.0, 24.0), res=(1920, 1080)):

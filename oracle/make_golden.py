@@ -203,6 +203,33 @@ def main():
         R.free(h)
         print("mixed_field_planes hits", int((hits["id"] >= 0).sum()))
 
+    golden_textured(R)
+
+
+def golden_textured(R):
+    """6. albedo textures (P6 and P3 files, a maxval below 255, unreadable files) through the reference's own loader,
+    Image reader and Mesh::evaluate_albedo."""
+    with tempfile.TemporaryDirectory() as td:
+        prims, lights, cam, textures, prim_tex, paths = S.textured_scene(td)
+        jp = os.path.join(td, "s.json")
+        S.scene_to_json(prims, lights, {"3": cam}, jp, texture_paths=paths)
+        h = R.load(jp)
+        assert R.num_meshes(h) == len(prims)
+        rays = R.primary_rays(h, "3")
+        W, H = cam["res"]
+        hits = R.trace_rays(h, rays)
+        out = dict(ids=hits["id"].reshape(H, W).astype(np.int16), dist=hits["dist"].reshape(H, W),
+                   u=hits["u"].reshape(H, W), v=hits["v"].reshape(H, W), prim_tex=prim_tex,
+                   shade_linear=R.shade_rays(h, rays).reshape(H, W, 3))
+        for ms in (0, 2):
+            out["render%d" % ms], out["render%d_md5" % ms] = render(R, h, "3", ms)
+        R.free(h)
+    np.savez_compressed(os.path.join(GOLD, "textured.npz"), **out)
+    print("textured hits", int((hits["id"] >= 0).sum()), out["render2_md5"])
+
 
 if __name__ == "__main__":
-    main()
+    if "--textured-only" in sys.argv:
+        golden_textured(bind.Ref())
+    else:
+        main()

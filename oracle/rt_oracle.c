@@ -397,6 +397,29 @@ static uint8_t unit_to_u8(double x) {
 static void albedo_u8(const rto_prim* m, uint8_t c[3]) {
     c[0] = unit_to_u8(m->albedo[0]); c[1] = unit_to_u8(m->albedo[1]); c[2] = unit_to_u8(m->albedo[2]);
 }
+/* Mesh::evaluate_albedo, s2899221/Code/mesh.cpp:21-45: texture (wrap, nearest) when there is one, else solid. */
+static void albedo_at(const rto_scene* sc, const rto_hit* hit, uint8_t c[3]) {
+    const rto_prim* m = &sc->prims[hit->id];
+    if (sc->prim_tex && sc->textures && sc->prim_tex[hit->id] >= 0 && sc->prim_tex[hit->id] < sc->n_textures) {
+        const rto_texture* t = &sc->textures[sc->prim_tex[hit->id]];
+        const int w = t->width, h = t->height;
+        if (w > 0 && h > 0) {
+            double u = hit->u, v = hit->v;
+            u = u - floor(u);
+            v = v - floor(v);
+            int x = (int)floor(u * (double)(w - 1));
+            int y = (int)floor(v * (double)(h - 1));
+            if (x < 0) x = 0;
+            if (x >= w) x = w - 1;
+            if (y < 0) y = 0;
+            if (y >= h) y = h - 1;
+            const uint8_t* px = t->rgb + ((size_t)y * (size_t)w + (size_t)x) * 3u;
+            c[0] = px[0]; c[1] = px[1]; c[2] = px[2];
+            return;
+        }
+    }
+    albedo_u8(m, c);
+}
 
 static uint8_t round_u8(double cc) {
     int ci = (int)round(cc);
@@ -468,7 +491,7 @@ static void shade_with(const rto_scene* sc, const rto_hit* hit, const double ray
     if (intensity > 1.0) intensity = 1.0;
 
     uint8_t base[3] = { 255, 255, 255 };
-    if (m) albedo_u8(m, base);
+    if (m) albedo_at(sc, hit, base);
     for (int c = 0; c < 3; ++c) rgb[c] = round_u8(intensity * (double)base[c]);
 }
 
@@ -497,7 +520,7 @@ static void trace_rec(const rto_scene* sc, const double o[3], const double d[3],
     const double ct = h.n[0]*vx + h.n[1]*vy + h.n[2]*vz;
     const double cosTheta = (0.0 < ct) ? ct : 0.0;
     double F0;
-    uint8_t base[3]; albedo_u8(m, base);
+    uint8_t base[3]; albedo_at(sc, &h, base);
     if (metallic <= 0.0) {
         const double r0 = (ior - 1.0) / (ior + 1.0);
         F0 = clampd(r0 * r0, 0.0, 1.0);

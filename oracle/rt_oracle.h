@@ -61,9 +61,14 @@ typedef struct rto_hit {
     double  u, v;
 } rto_hit;
 
+/* Albedo texture as Image keeps it (utils.h:129-151): 8-bit RGB, rows top to bottom. */
+typedef struct rto_texture { int32_t width, height; const uint8_t* rgb; } rto_texture;
+
 typedef struct rto_scene {
     const rto_prim*  prims;  int64_t n_prims;
     const rto_light* lights; int64_t n_lights;
+    const rto_texture* textures; int64_t n_textures;   /* may be NULL / 0 */
+    const int32_t* prim_tex;                           /* per primitive: index into textures or -1; may be NULL */
 } rto_scene;
 
 /* 32-byte BVH node shared with the product's flattened layout: internal nodes have count == 0 and

@@ -22,7 +22,7 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 DEVICE_SOURCES = ["rt_kernels.hip"]
-HOST_SOURCES = ["rt_capi.cpp", "rt_scene.cpp", "rt_prep.cpp", "rt_bvh.cpp", "rt_json.cpp"]
+HOST_SOURCES = ["rt_capi.cpp", "rt_scene.cpp", "rt_prep.cpp", "rt_bvh.cpp", "rt_json.cpp", "rt_image.cpp"]
 
 
 def hipcc():

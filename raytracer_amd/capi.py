@@ -57,6 +57,10 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.c_void_p)]
+
+
 class Timing(C.Structure):
     _fields_ = [("primary_ms", C.c_double), ("shadow_ms", C.c_double), ("resolve_ms", C.c_double), ("bounce_ms", C.c_double),
                 ("primary_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("resolve_launches", C.c_uint32),
@@ -70,6 +74,9 @@ SYMBOLS = [
     ("rt_scene_create", C.c_int, [_VP, _U64, _VP, _U32, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_load_json", C.c_int, [C.c_char_p, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_load_json_text", C.c_int, [C.c_char_p, _U64, C.POINTER(BuildOpts), C.POINTER(_VP)]),
+    ("rt_scene_set_textures", C.c_int, [_VP, _VP, _U32, _VP]),
+    ("rt_scene_get_texture", C.c_int, [_VP, _U64, _VP]),
+    ("rt_image_read_ppm", C.c_int, [C.c_char_p, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), _VP, _U64]),
     ("rt_scene_destroy", C.c_int, [_VP]),
     ("rt_scene_get_info", C.c_int, [_VP, C.POINTER(SceneInfo)]),
     ("rt_scene_get_prims", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U64)]),
@@ -176,6 +183,15 @@ def pixel_rays(cam, pxy):
     return out
 
 
+def read_ppm(path):
+    """(pixels (h, w, 3) uint8, maxval) through the library's PPM reader; raises RtError as the reference's Image throws."""
+    w, h, mv = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib().rt_image_read_ppm(str(path).encode(), C.byref(w), C.byref(h), C.byref(mv), None, 0))
+    px = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    _check(lib().rt_image_read_ppm(str(path).encode(), C.byref(w), C.byref(h), C.byref(mv), _ptr(px), px.size))
+    return px, mv.value
+
+
 def prim_aabb(prim):
     prim = np.ascontiguousarray(prim, dtype=PRIM_DT).reshape(1)
     out = (C.c_double * 6)()
@@ -210,6 +226,24 @@ class Scene:
         h = C.c_void_p()
         _check(lib().rt_scene_load_json(str(path).encode(), C.byref(opts), C.byref(h)))
         return cls(h)
+
+    def set_textures(self, textures, prim_texture):
+        """textures: list of (h, w, 3) uint8 arrays; prim_texture: index per primitive, -1 = none."""
+        arrs = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
+        table = (Texture * max(len(arrs), 1))()
+        for k, a in enumerate(arrs):
+            assert a.ndim == 3 and a.shape[2] == 3
+            table[k] = Texture(a.shape[1], a.shape[0], a.ctypes.data)
+        pt = np.ascontiguousarray(prim_texture, dtype=np.int32)
+        _check(lib().rt_scene_set_textures(self.h, table, len(arrs), _ptr(pt)))
+
+    def texture(self, prim_id):
+        t = Texture()
+        _check(lib().rt_scene_get_texture(self.h, prim_id, C.byref(t)))
+        if t.width == 0:
+            return None
+        buf = (C.c_uint8 * (t.width * t.height * 3)).from_address(t.rgb)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(t.height, t.width, 3).copy()
 
     @classmethod
     def load_json_text(cls, text, max_leaf=0, sah_bins=0):
@@ -389,12 +423,13 @@ class Context:
         _check(lib().rt_intersect_prim_host(self.h, _ptr(prim), _ptr(rays6), len(rays6), _ptr(rec)))
         return rec
 
-    def shade_hits(self, hits8, view3):
-        hits8 = np.ascontiguousarray(hits8, dtype=np.float64).reshape(-1, 8)
+    def shade_hits(self, hits10, view3):
+        """hits10: point, normal, primitive id, u, v, has-uv flag per hit; view3: origin of the ray that found it."""
+        hits10 = np.ascontiguousarray(hits10, dtype=np.float64).reshape(-1, 10)
         view3 = np.ascontiguousarray(view3, dtype=np.float64).reshape(-1, 3)
-        assert len(hits8) == len(view3)
-        rgb = np.empty((len(hits8), 3), dtype=np.uint8)
-        _check(lib().rt_shade_hits_host(self.h, _ptr(hits8), _ptr(view3), len(hits8), _ptr(rgb)))
+        assert len(hits10) == len(view3)
+        rgb = np.empty((len(hits10), 3), dtype=np.uint8)
+        _check(lib().rt_shade_hits_host(self.h, _ptr(hits10), _ptr(view3), len(hits10), _ptr(rgb)))
         return rgb
 
     def render_samples(self, cam, spp, seed=1, max_scatters=2, min_scatter_intensity=0.0):

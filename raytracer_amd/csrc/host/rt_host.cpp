@@ -604,6 +604,15 @@ bool RayTracer::load_from_json(const std::string& json_filepath) {
             default: break;
         }
     }
+    rebuild_mesh_ptrs();
+    for (size_t i = 0; i < m_scene_mesh_ptrs.size(); ++i) {
+        rt_texture t;
+        if (rt_scene_get_texture(s, i, &t) == RT_OK && t.width > 0) {
+            std::unique_ptr<Image> img(new Image(t.width, t.height));
+            img->assign_rgb(t.rgb);
+            const_cast<Mesh*>(m_scene_mesh_ptrs[i])->setAlbedoTexture(std::move(img));
+        }
+    }
     rt_scene_info info;
     rt_scene_get_info(s, &info);
     for (uint32_t k = 0; k < info.n_cameras; ++k) {
@@ -641,6 +650,20 @@ GpuScene& RayTracer::gpu() const {
         for (const PointLight& L : m_light_order) lights.push_back(rt_light{ { L.location.x, L.location.y, L.location.z }, L.radiant_intensity });
         if (int rc = rt_scene_create(descs.data(), descs.size(), lights.data(), static_cast<uint32_t>(lights.size()), nullptr, &m_gpu->scene))
             rt_host::gpu_fail("scene build", rc);
+        // textures the caller attached to its meshes (Mesh::setAlbedoTexture)
+        std::vector<rt_texture> tex; std::vector<std::vector<unsigned char>> pixels; std::vector<int32_t> prim_tex(descs.size(), -1);
+        for (size_t i = 0; i < m_scene_mesh_ptrs.size(); ++i) {
+            const Image* img = m_scene_mesh_ptrs[i]->albedoTexture();
+            if (!img || img->width() <= 0 || img->height() <= 0) continue;
+            pixels.emplace_back();
+            for (const Pixel& p : img->pixels()) { pixels.back().push_back(p.r); pixels.back().push_back(p.g); pixels.back().push_back(p.b); }
+            prim_tex[i] = static_cast<int32_t>(tex.size());
+            tex.push_back(rt_texture{ img->width(), img->height(), nullptr });
+        }
+        for (size_t k = 0; k < tex.size(); ++k) tex[k].rgb = pixels[k].data();
+        if (!tex.empty())
+            if (int rc = rt_scene_set_textures(m_gpu->scene, tex.data(), static_cast<uint32_t>(tex.size()), prim_tex.data()))
+                rt_host::gpu_fail("scene textures", rc);
     }
     m_gpu->upload();
     return *m_gpu;
@@ -689,16 +712,17 @@ std::vector<Pixel> RayTracer::shade(const std::vector<Hit>& hits, const std::vec
     if (hits.size() != view_rays.size()) throw std::invalid_argument("shade: one view ray per hit");
     std::vector<Pixel> out(hits.size(), Pixel{ 0, 0, 0 });
     if (hits.empty() || m_light_order.empty()) return out;               // raytracer.cpp:197-202
-    std::vector<double> h8(hits.size() * 8, 0.0), v3(hits.size() * 3);
+    std::vector<double> h8(hits.size() * 10, 0.0), v3(hits.size() * 3);
     for (size_t i = 0; i < hits.size(); ++i) {
         const Hit& h = hits[i];
-        double* o = &h8[i * 8];
+        double* o = &h8[i * 10];
         o[6] = -1.0;                                                     // black unless the hit carries surface data (raytracer.cpp:161)
         if (h.hasDistanceAlongRay() && h.hasSurfaceNormal() && h.hasIntersectionPoint()) {
             const HitVec3& p = h.getIntersectionPoint(); const HitVec3& n = h.getSurfaceNormal();
             o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = n.x; o[4] = n.y; o[5] = n.z;
             const int id = h.hasMesh() ? index_of(h.getMesh()) : -1;
             o[6] = id >= 0 ? static_cast<double>(id) : -2.0;             // no (known) mesh: default material, white
+            if (h.hasUV()) { o[7] = h.getU(); o[8] = h.getV(); o[9] = 1.0; }
         }
         const RayVec3& c = view_rays[i].getPosition();
         v3[i*3] = c.x; v3[i*3 + 1] = c.y; v3[i*3 + 2] = c.z;

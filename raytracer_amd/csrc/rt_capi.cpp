@@ -48,6 +48,7 @@ struct rt_ctx {
     DevScene sc{};
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
+    uint8_t* d_texels = nullptr; rt_tex_rec* d_tex_table = nullptr;
     uint8_t* d_gamma = nullptr;            // 256 bytes of the display transfer table, then 256 bytes of identity
     unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
     uint32_t queue_used = kQueueSlots;     // slots consumed since the last zeroing
@@ -78,7 +79,9 @@ struct rt_ctx {
         if (d_recs) (void)hipFree(d_recs);
         if (d_mats) (void)hipFree(d_mats);
         if (d_lights) (void)hipFree(d_lights);
-        d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr;
+        if (d_texels) (void)hipFree(d_texels);
+        if (d_tex_table) (void)hipFree(d_tex_table);
+        d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr; d_texels = nullptr; d_tex_table = nullptr;
         have_scene = false;
     }
     int need(int slot, size_t bytes, void** out) {
@@ -171,8 +174,10 @@ int rt_scene_load_json(const char* path, const rt_build_opts* opts, rt_scene** o
     if (!s) return fail(RT_ERR_LIMIT, "out of memory");
     try {
         std::string err;
-        int rc = rt_parse_scene_file(path, s->prims, s->lights, s->cameras, err);
+        std::vector<std::string> tex_paths;
+        int rc = rt_parse_scene_file(path, s->prims, s->lights, s->cameras, tex_paths, err);
         if (rc == RT_OK) rc = rt_scene_finalize(s, opts);
+        if (rc == RT_OK) rt_scene_attach_textures(s, tex_paths);
         if (rc != RT_OK) { delete s; return fail(rc, err.empty() ? "scene load failed" : err); }
     } catch (const std::exception& e) { delete s; return fail(RT_ERR_LIMIT, e.what()); }
     *out = s;
@@ -186,11 +191,59 @@ int rt_scene_load_json_text(const char* text, uint64_t len, const rt_build_opts*
     if (!s) return fail(RT_ERR_LIMIT, "out of memory");
     try {
         std::string err;
-        int rc = rt_parse_scene_text(text, static_cast<size_t>(len), s->prims, s->lights, s->cameras, err);
+        std::vector<std::string> tex_paths;
+        int rc = rt_parse_scene_text(text, static_cast<size_t>(len), s->prims, s->lights, s->cameras, tex_paths, err);
         if (rc == RT_OK) rc = rt_scene_finalize(s, opts);
+        if (rc == RT_OK) rt_scene_attach_textures(s, tex_paths);
         if (rc != RT_OK) { delete s; return fail(rc, err.empty() ? "scene load failed" : err); }
     } catch (const std::exception& e) { delete s; return fail(RT_ERR_LIMIT, e.what()); }
     *out = s;
+    return RT_OK;
+}
+
+int rt_scene_set_textures(rt_scene* scene, const rt_texture* textures, uint32_t n_textures, const int32_t* prim_texture) {
+    if (!scene || (n_textures && (!textures || !prim_texture))) return fail(RT_ERR_INVALID, "null argument");
+    try {
+        scene->texels.clear(); scene->tex_table.clear();
+        scene->prim_tex.assign(scene->prims.size(), -1);
+        for (uint32_t t = 0; t < n_textures; ++t) {
+            if (textures[t].width <= 0 || textures[t].height <= 0 || !textures[t].rgb) return fail(RT_ERR_INVALID, "empty texture");
+            const size_t bytes = static_cast<size_t>(textures[t].width) * static_cast<size_t>(textures[t].height) * 3u;
+            scene->tex_table.push_back(rt_tex_rec{ scene->texels.size(), textures[t].width, textures[t].height });
+            scene->texels.insert(scene->texels.end(), textures[t].rgb, textures[t].rgb + bytes);
+        }
+        for (size_t i = 0; i < scene->prims.size() && n_textures; ++i) {
+            if (prim_texture[i] >= static_cast<int32_t>(n_textures)) return fail(RT_ERR_INVALID, "texture index out of range");
+            scene->prim_tex[i] = prim_texture[i] < 0 ? -1 : prim_texture[i];
+        }
+        for (size_t i = 0; i < scene->mats.size(); ++i) scene->mats[i].tex = scene->prim_tex[i];
+    } catch (const std::exception& e) { return fail(RT_ERR_LIMIT, e.what()); }
+    return RT_OK;
+}
+
+int rt_scene_get_texture(const rt_scene* scene, uint64_t prim_id, rt_texture* out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (prim_id >= scene->prims.size()) return fail(RT_ERR_INVALID, "primitive id out of range");
+    out->width = 0; out->height = 0; out->rgb = nullptr;
+    const int32_t t = prim_id < scene->prim_tex.size() ? scene->prim_tex[prim_id] : -1;
+    if (t >= 0) {
+        out->width = scene->tex_table[t].width; out->height = scene->tex_table[t].height;
+        out->rgb = scene->texels.data() + scene->tex_table[t].offset;
+    }
+    return RT_OK;
+}
+
+int rt_image_read_ppm(const char* path, int32_t* width, int32_t* height, int32_t* maxval, uint8_t* rgb_or_null, uint64_t capacity) {
+    if (!path || !width || !height || !maxval) return fail(RT_ERR_INVALID, "null argument");
+    try {
+        std::vector<uint8_t> rgb; std::string err;
+        if (!rt_load_ppm(path, *width, *height, *maxval, rgb, err))
+            return fail(err.rfind("Failed to open", 0) == 0 ? RT_ERR_IO : RT_ERR_PARSE, err);
+        if (rgb_or_null) {
+            if (capacity < rgb.size()) return fail(RT_ERR_LIMIT, "pixel buffer too small");
+            std::memcpy(rgb_or_null, rgb.data(), rgb.size());
+        }
+    } catch (const std::exception& e) { return fail(RT_ERR_LIMIT, e.what()); }
     return RT_OK;
 }
 
@@ -385,6 +438,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (rc == RT_OK) rc = upload(scene->recs, &ctx->d_recs);
     if (rc == RT_OK) rc = upload(scene->mats, &ctx->d_mats);
     if (rc == RT_OK) rc = upload(scene->lights, &ctx->d_lights);
+    if (rc == RT_OK) rc = upload(scene->texels, &ctx->d_texels);
+    if (rc == RT_OK) rc = upload(scene->tex_table, &ctx->d_tex_table);
     if (rc != RT_OK) { ctx->free_scene(); return rc; }
     DevScene& d = ctx->sc;
     d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
@@ -393,6 +448,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.n_loose = static_cast<uint32_t>(scene->n_loose);
     d.n_lights = static_cast<uint32_t>(scene->lights.size());
     d.n_prims = static_cast<uint32_t>(scene->prims.size());
+    d.texels = ctx->d_texels; d.tex_table = ctx->d_tex_table;
+    d.n_textures = static_cast<uint32_t>(scene->tex_table.size());
     // round the radius up: the padding must not shrink through the conversion
     d.radius = std::nextafterf(static_cast<float>(scene->info.radius), INFINITY);
     if (!std::isfinite(d.radius)) d.radius = 3.0e38f;
@@ -423,13 +480,14 @@ uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
 int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
     const size_t planes = 7 + n_batch;
     void* base = nullptr;
-    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t)) + 256, &base)) return rc;
+    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t) + sizeof(uint32_t)) + 256, &base)) return rc;
     double* d = static_cast<double*>(base);
     fb.px = d; fb.py = d + n; fb.pz = d + 2*n; fb.nx = d + 3*n; fb.ny = d + 4*n; fb.nz = d + 5*n;
     fb.lighting = d + 6*n; fb.contrib = d + 7*n;
     fb.id = reinterpret_cast<int32_t*>(d + planes * n);
     fb.n = n;
     fb.ray = nullptr; fb.rawn = nullptr; fb.alive = nullptr; fb.level = 0;
+    fb.albedo = ctx->sc.n_textures ? reinterpret_cast<uint32_t*>(fb.id + n) : nullptr;
     return RT_OK;
 }
 
@@ -555,11 +613,11 @@ int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double*
     return RT_OK;
 }
 
-int rt_shade_hits(rt_ctx* ctx, const double* hits8_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev) {
+int rt_shade_hits(rt_ctx* ctx, const double* hits10_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev) {
     if (int rc = need_scene(ctx)) return rc;
-    if (n && (!hits8_dev || !view3_dev || !rgb_dev)) return fail(RT_ERR_INVALID, "null argument");
+    if (n && (!hits10_dev || !view3_dev || !rgb_dev)) return fail(RT_ERR_INVALID, "null argument");
     if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many hits for one launch");
-    RT_HIP(rt_launch_shade_hits(ctx->stream, &ctx->sc, hits8_dev, view3_dev, n, rgb_dev, ctx->d_ctr));
+    RT_HIP(rt_launch_shade_hits(ctx->stream, &ctx->sc, hits10_dev, view3_dev, n, rgb_dev, ctx->d_ctr));
     return RT_OK;
 }
 
@@ -759,15 +817,15 @@ int rt_trace_rays_full_host(rt_ctx* ctx, const double* rays6_host, uint64_t n, d
     return RT_OK;
 }
 
-int rt_shade_hits_host(rt_ctx* ctx, const double* hits8_host, const double* view3_host, uint64_t n, uint8_t* rgb_host) {
+int rt_shade_hits_host(rt_ctx* ctx, const double* hits10_host, const double* view3_host, uint64_t n, uint8_t* rgb_host) {
     if (int rc = need_scene(ctx)) return rc;
     if (n == 0) return RT_OK;
-    if (!hits8_host || !view3_host || !rgb_host) return fail(RT_ERR_INVALID, "null argument");
+    if (!hits10_host || !view3_host || !rgb_host) return fail(RT_ERR_INVALID, "null argument");
     void *d_hits = nullptr, *d_view = nullptr, *d_rgb = nullptr;
-    if (int rc = ctx->need(0, n * 8 * sizeof(double), &d_hits)) return rc;
+    if (int rc = ctx->need(0, n * 10 * sizeof(double), &d_hits)) return rc;
     if (int rc = ctx->need(1, n * 3 * sizeof(double), &d_view)) return rc;
     if (int rc = ctx->need(2, n * 3, &d_rgb)) return rc;
-    RT_HIP(hipMemcpyAsync(d_hits, hits8_host, n * 8 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipMemcpyAsync(d_hits, hits10_host, n * 10 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(hipMemcpyAsync(d_view, view3_host, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (int rc = rt_shade_hits(ctx, static_cast<const double*>(d_hits), static_cast<const double*>(d_view), n, static_cast<uint8_t*>(d_rgb))) return rc;
     RT_HIP(hipMemcpyAsync(rgb_host, d_rgb, n * 3, hipMemcpyDeviceToHost, ctx->stream));

@@ -22,7 +22,9 @@ struct DevScene {
     const rt_mat_rec*  mats;       // by primitive id
     const rt_light*    lights;
     const uint8_t*     gamma;      // 256-entry table
-    uint32_t n_nodes, n_slots, n_loose, n_lights, n_prims;
+    const uint8_t*     texels;     // albedo textures, 8-bit RGB
+    const rt_tex_rec*  tex_table;
+    uint32_t n_nodes, n_slots, n_loose, n_lights, n_prims, n_textures;
     float radius;                  // max |coordinate| of the scene: scales the box padding
 };
 
@@ -58,6 +60,7 @@ struct FrameBufs {
     double *rawn;                  // 3 planes: the intersector's normal as it left the primitive test
     uint8_t *alive;                // levels >= 1: this slot still carries a ray
     int level;
+    uint32_t *albedo;              // scenes with textures only: albedo under the hit, r | g << 8 | b << 16
 };
 
 // Per-level results of a mirror-bounce frame, folded into the final colour at the end.

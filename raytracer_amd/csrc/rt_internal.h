@@ -22,9 +22,13 @@ struct rt_prim_rec {
 // (s2899221/Code/mesh.h:36-59, mesh.cpp:15-45).
 struct rt_mat_rec {
     double  metallic, roughness, ior;
-    uint8_t albedo[3];
-    uint8_t pad[5];
+    uint8_t albedo[3];             // solid colour, already 8 bit (mesh.cpp:40-43)
+    uint8_t pad;
+    int32_t tex;                   // index into the scene's texture table, -1 = solid colour
 };
+
+// One albedo texture inside the scene's texel pool (8-bit RGB, rows top to bottom).
+struct rt_tex_rec { uint64_t offset; int32_t width, height; };
 
 #define RT_STACK_DEPTH 32          // traversal stack entries per lane; the builder keeps depth <= 31
 #define RT_MAX_SCATTERS 8

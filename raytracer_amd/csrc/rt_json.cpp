@@ -31,6 +31,7 @@ struct Node {
     double number = 0.0;
     bool unsigned_integer_text = false;        // token was digits only
     std::string text;                          // string value
+    std::string raw;                           // string value exactly as written between the quotes
     std::vector<Member> members;               // object, in document order
     std::vector<std::unique_ptr<Node>> items;  // array
 };
@@ -43,13 +44,16 @@ struct Parser {
     bool string(std::string& out) {
         if (p >= end || *p != '"') return fail("expected string");
         ++p; out.clear();
+        const char* first = p;
         while (p < end && *p != '"') {
             if (*p == '\\' && p + 1 < end) { out.push_back(p[1]); p += 2; }   // escapes are kept verbatim minus the backslash
             else out.push_back(*p++);
         }
         if (p >= end) return fail("unterminated string");
+        last_raw.assign(first, p);
         ++p; return true;
     }
+    std::string last_raw;
 
     bool value(Node& n) {
         if (++depth > 200) return fail("nesting too deep");
@@ -86,7 +90,7 @@ struct Parser {
                 ok = fail("expected ',' or ']'"); break;
             }
         } else if (c == '"') {
-            n.type = Node::String; ok = string(n.text);
+            n.type = Node::String; ok = string(n.text); n.raw = last_raw;
         } else if (std::isdigit(static_cast<unsigned char>(c)) || c == '-' || c == '+' || c == '.') {
             // the reference accepts any run of [-+eE0-9.] and hands it to std::stod
             const char* s = p; bool digits_only = true;
@@ -178,10 +182,28 @@ void default_material(rt_prim_desc& d) {
     d.albedo[0] = d.albedo[1] = d.albedo[2] = 1.0;
 }
 
+// first member named `key` whose value is a string, document order, any depth
+const Node* find_string_node(const Node& n, const char* key) {
+    if (n.type == Node::Object) {
+        for (const Member& m : n.members) {
+            if (m.first == key && m.second->type == Node::String) return m.second.get();
+            if (const Node* r = find_string_node(*m.second, key)) return r;
+        }
+    } else if (n.type == Node::Array) {
+        for (const auto& it : n.items) if (const Node* r = find_string_node(*it, key)) return r;
+    }
+    return nullptr;
+}
+
+// The primitive being read leaves its texture path here (mesh.cpp:91-97: the text between the quotes, not unescaped).
+thread_local std::string g_texture_path;
+
 void read_material(const Node& obj, rt_prim_desc& d) {
     default_material(d);
+    g_texture_path.clear();
     const Node* m = find_block(obj, "material");
     if (!m) return;
+    if (const Node* t = find_string_node(*m, "albedo_texture_ppm")) g_texture_path = t->raw;
     get_number(*m, "alpha", d.alpha);
     get_number(*m, "metallic", d.metallic);
     get_number(*m, "roughness", d.roughness);
@@ -195,7 +217,7 @@ template <class Fn> void for_each_object(const Node& cls, Fn fn) {
         if (all_digits(m.first) && m.second->type == Node::Object) fn(m.first, *m.second);
 }
 
-void read_trs(const Node& obj, int kind, std::vector<rt_prim_desc>& out) {
+void read_trs(const Node& obj, int kind, std::vector<rt_prim_desc>& out, std::vector<std::string>& tex) {
     rt_prim_desc d; std::memset(&d, 0, sizeof(d));
     d.kind = kind;
     double t[3] = { 0, 0, 0 }, s[3] = { 1, 1, 1 }, r = 0, p = 0, y = 0;
@@ -205,6 +227,7 @@ void read_trs(const Node& obj, int kind, std::vector<rt_prim_desc>& out) {
     d.q[0] = t[0]; d.q[1] = t[1]; d.q[2] = t[2]; d.q[3] = r; d.q[4] = p; d.q[5] = y; d.q[6] = s[0]; d.q[7] = s[1]; d.q[8] = s[2];
     read_material(obj, d);
     out.push_back(d);
+    tex.push_back(g_texture_path);
 }
 
 bool read_file(const char* path, std::string& text) {
@@ -224,14 +247,14 @@ void camera_defaults(rt_camera& c) {
 } // namespace
 
 int rt_parse_scene_file(const char* path, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
-                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err) {
+                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::vector<std::string>& tex_paths, std::string& err) {
     std::string text;
     if (!read_file(path, text)) { err = std::string("cannot open ") + path; return RT_ERR_IO; }
-    return rt_parse_scene_text(text.data(), text.size(), prims, lights, cameras, err);
+    return rt_parse_scene_text(text.data(), text.size(), prims, lights, cameras, tex_paths, err);
 }
 
 int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
-                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err) {
+                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::vector<std::string>& tex_paths, std::string& err) {
     Node root;
     Parser ps{ text, text + len, std::string() };
     if (!ps.value(root)) {
@@ -241,11 +264,11 @@ int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>&
         root = Node();
     }
 
-    prims.clear(); lights.clear(); cameras.clear();
+    prims.clear(); lights.clear(); cameras.clear(); tex_paths.clear();
     if (const Node* mesh = find_block(root, "MESH")) {
         // primitive-id order of rebuild_mesh_ptrs: cubes, planes, cylinders, spheres (raytracer.cpp:20-27)
         if (const Node* c = find_block(*mesh, "Cube"))
-            for_each_object(*c, [&](const std::string&, const Node& o) { read_trs(o, RT_CUBE, prims); });
+            for_each_object(*c, [&](const std::string&, const Node& o) { read_trs(o, RT_CUBE, prims, tex_paths); });
         if (const Node* c = find_block(*mesh, "Plane"))
             for_each_object(*c, [&](const std::string&, const Node& o) {
                 const Node* corners = find_block(o, "corners");
@@ -265,9 +288,10 @@ int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>&
                 if (n < 4) d.reserved = 1;            // kept, never hit (mesh.cpp:796)
                 read_material(o, d);
                 prims.push_back(d);
+                tex_paths.push_back(g_texture_path);
             });
         if (const Node* c = find_block(*mesh, "Cylinder"))
-            for_each_object(*c, [&](const std::string&, const Node& o) { read_trs(o, RT_CYLINDER, prims); });
+            for_each_object(*c, [&](const std::string&, const Node& o) { read_trs(o, RT_CYLINDER, prims, tex_paths); });
         if (const Node* c = find_block(*mesh, "Sphere"))
             for_each_object(*c, [&](const std::string&, const Node& o) {
                 rt_prim_desc d; std::memset(&d, 0, sizeof(d));
@@ -277,6 +301,7 @@ int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>&
                 for (int k = 0; k < 3; ++k) { d.q[k] = l[k]; d.q[3 + k] = s[k]; }
                 read_material(o, d);
                 prims.push_back(d);
+                tex_paths.push_back(g_texture_path);
             });
     }
     if (const Node* cam = find_block(root, "CAMERA"))

@@ -506,21 +506,40 @@ DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m
     return light_value(L, m, px, py, pz, nx, ny, nz, sr.dx, sr.dy, sr.dz, view_ox, view_oy, view_oz);
 }
 
+// Mesh::evaluate_albedo (mesh.cpp:21-45) as r | g << 8 | b << 16: the texel under (u, v) - wrap, nearest,
+// floor(u * (w - 1)) - when the primitive carries a texture, its solid colour otherwise.
+DEV uint32_t solid_albedo(const rt_mat_rec& m) {
+    return static_cast<uint32_t>(m.albedo[0]) | static_cast<uint32_t>(m.albedo[1]) << 8 | static_cast<uint32_t>(m.albedo[2]) << 16;
+}
+DEV uint32_t albedo_at(const DevScene& sc, const rt_mat_rec& m, double u, double v) {
+    if (m.tex < 0) return solid_albedo(m);
+    const rt_tex_rec t = sc.tex_table[m.tex];
+    u = u - __builtin_floor(u); v = v - __builtin_floor(v);
+    int x = static_cast<int>(__builtin_floor(u * static_cast<double>(t.width - 1)));
+    int y = static_cast<int>(__builtin_floor(v * static_cast<double>(t.height - 1)));
+    if (x < 0) x = 0;
+    if (x >= t.width) x = t.width - 1;
+    if (y < 0) y = 0;
+    if (y >= t.height) y = t.height - 1;
+    const uint8_t* px = sc.texels + t.offset + (static_cast<size_t>(y) * t.width + x) * 3u;
+    return static_cast<uint32_t>(px[0]) | static_cast<uint32_t>(px[1]) << 8 | static_cast<uint32_t>(px[2]) << 16;
+}
+
 // Ambient, clamp, albedo, 8-bit quantisation (raytracer.cpp:262-278); packed r | g << 8 | b << 16.
-DEV uint32_t finish_shade(const rt_mat_rec& m, double lighting) {
+DEV uint32_t finish_shade(const rt_mat_rec& m, uint32_t albedo, double lighting) {
     const double metallic = clampd(m.metallic, 0.0, 1.0);
     double intensity = (1.0 - metallic) * 0.05 + lighting;
     if (intensity < 0.0) intensity = 0.0;
     if (intensity > 1.0) intensity = 1.0;
-    return round_u8(intensity * static_cast<double>(m.albedo[0]))
-         | round_u8(intensity * static_cast<double>(m.albedo[1])) << 8
-         | round_u8(intensity * static_cast<double>(m.albedo[2])) << 16;
+    return round_u8(intensity * static_cast<double>(albedo & 255u))
+         | round_u8(intensity * static_cast<double>((albedo >> 8) & 255u)) << 8
+         | round_u8(intensity * static_cast<double>((albedo >> 16) & 255u)) << 16;
 }
 
 // RayTracer::shade, raytracer.cpp:159-279, all lights in order inside one lane (megakernel path).
 template <bool COUNT>
-DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec& m, double view_ox, double view_oy, double view_oz,
-                            uint2* lds_stack, ShadeCounters& ctr) {
+DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec& m, uint32_t albedo, double view_ox, double view_oy,
+                            double view_oz, uint2* lds_stack, ShadeCounters& ctr) {
     if (sc.n_lights == 0) return 0;
     double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);
     double lighting = 0.0;
@@ -528,14 +547,15 @@ DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec&
         const rt_light L = sc.lights[li];
         lighting += light_term<COUNT>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
     }
-    return finish_shade(m, lighting);
+    return finish_shade(m, albedo, lighting);
 }
 
+// h must carry u, v when the scene has textures.
 template <bool COUNT>
 DEV uint32_t shade(const DevScene& sc, const HitD& h, int32_t id, double view_ox, double view_oy, double view_oz,
                    uint2* lds_stack, ShadeCounters& ctr) {
     const rt_mat_rec m = sc.mats[id];
-    return shade_material<COUNT>(sc, h, m, view_ox, view_oy, view_oz, lds_stack, ctr);
+    return shade_material<COUNT>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, lds_stack, ctr);
 }
 
 // Camera::pixelToRay, persp_camera.cpp:94-118 (effective sensor size precomputed on the host).
@@ -642,9 +662,10 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 // counter), then the wave advances all its walks by one while-while round.  Finished lanes are only swapped once
 // RT_REFILL_MIN of them have piled up, so that the result / set-up code also runs on a well-filled wave.
 // MODE 0 - closest hits: ray i = lane (i % 64) of tile (i / 64) of the pixel map; writes ids / dist (optional) and,
-//          with RECORD >= 1, the surface record (point, re-normalised normal, id) the shadow pass starts from.
-//          RECORD == 2 is a level of a mirror-bounce frame: level 0 also stores its camera rays, deeper levels take
+//          with RECORD != 0, the surface record (point, re-normalised normal, id) the shadow pass starts from.
+//          RECORD & 2: a level of a mirror-bounce frame - level 0 also stores its camera rays, deeper levels take
 //          their rays from the slots (left there by k_bounce_resolve), and the raw normal is kept for the Fresnel term.
+//          RECORD & 4: the scene has textures - the albedo under the hit's (u, v) is stored with the record.
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
 template <int MODE, bool COUNT, int RECORD>
@@ -683,11 +704,12 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         if (hit) {
                             HitD h;
                             const rt_prim_rec* rec = sc.recs + w.best.slot;
-                            hit_record<true>(rec, rec->kind, w.r, h);
+                            hit_record<true, (RECORD & 4) != 0>(rec, rec->kind, w.r, h);
+                            if (RECORD & 4) fb.albedo[out] = albedo_at(sc, sc.mats[w.best.id], h.u, h.v);
                             double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
                             fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
                             fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
-                            if (RECORD == 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
+                            if (RECORD & 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
                         }
                     }
                 } else {
@@ -739,7 +761,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         if (MODE == 0) {
                             RayD r;
                             bool have = true;
-                            if (RECORD == 2 && fb.level > 0) {
+                            if ((RECORD & 2) && fb.level > 0) {
                                 // a bounce level: the ray was left in the slot by the level above
                                 if (fb.alive[out]) {
                                     r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
@@ -748,7 +770,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                 } else { have = false; fb.id[out] = -1; }
                             } else {
                                 primary_ray(cam, p.x, p.y, r);
-                                if (RECORD == 2) {
+                                if (RECORD & 2) {
                                     fb.ray[out] = r.ox; fb.ray[fb.n + out] = r.oy; fb.ray[2*fb.n + out] = r.oz;
                                     fb.ray[3*fb.n + out] = r.dx; fb.ray[4*fb.n + out] = r.dy; fb.ray[5*fb.n + out] = r.dz;
                                 }
@@ -782,7 +804,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     }
     const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
     if (MODE == 0) {
-        const bool bounce_level = RECORD == 2 && fb.level > 0;
+        const bool bounce_level = (RECORD & 2) && fb.level > 0;
         add_counter(ctr, shard, bounce_level ? F_BOUNCE : F_PRIMARY, n_cast);
         add_counter(ctr, shard, F_HITS, bounce_level ? 0u : n_hit);
         if (COUNT) { add_counter(ctr, shard, F_VN_P, w.vn); add_counter(ctr, shard, F_VP_P, w.vp); }
@@ -806,7 +828,8 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, FrameBufs fb, uint
     double lighting = first ? 0.0 : fb.lighting[i];
     for (uint32_t j = 0; j < n_batch; ++j) lighting += fb.contrib[static_cast<size_t>(j) * fb.n + i];
     if (!last) { fb.lighting[i] = lighting; return; }
-    const uint32_t c = finish_shade(sc.mats[id], lighting);
+    const rt_mat_rec m = sc.mats[id];
+    const uint32_t c = finish_shade(m, fb.albedo ? fb.albedo[i] : solid_albedo(m), lighting);
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
 }
 
@@ -842,9 +865,9 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
         if (SHADE) {
             uint32_t c = 0;
             if (hit) {
-                HitD h;
+                HitD h; h.u = 0.0; h.v = 0.0;
                 const rt_prim_rec* rec = sc.recs + b.slot;
-                hit_record<true>(rec, rec->kind, r, h);
+                hit_record<true, true>(rec, rec->kind, r, h);
                 c = shade<COUNT>(sc, h, b.id, r.ox, r.oy, r.oz, my_stack, sctr);
             }
             rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
@@ -880,25 +903,30 @@ __global__ void __launch_bounds__(64) k_intersect_one(const rt_prim_rec* __restr
     o[12] = hit ? h.u : 0.0; o[13] = hit ? h.v : 0.0; o[14] = 0.0; o[15] = 0.0;
 }
 
-// RayTracer::shade for caller-supplied hits: 8 doubles each (point, normal, primitive id, unused) and a view origin
-// (3 doubles) per hit; linear 8-bit colour out.
+// RayTracer::shade for caller-supplied hits: 10 doubles each (point, normal, primitive id, u, v, has-uv flag) and a
+// view origin (3 doubles) per hit; linear 8-bit colour out.
 __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __restrict__ hits, const double* __restrict__ view,
                                                    uint64_t n, uint8_t* __restrict__ rgb, rt_counters* ctr) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
     ShadeCounters sctr = { 0, 0, 0 };
     if (i < n) {
         HitD h;
-        h.px = hits[i*8]; h.py = hits[i*8 + 1]; h.pz = hits[i*8 + 2];
-        h.nx = hits[i*8 + 3]; h.ny = hits[i*8 + 4]; h.nz = hits[i*8 + 5];
-        const double idf = hits[i*8 + 6];
+        h.px = hits[i*10]; h.py = hits[i*10 + 1]; h.pz = hits[i*10 + 2];
+        h.nx = hits[i*10 + 3]; h.ny = hits[i*10 + 4]; h.nz = hits[i*10 + 5];
+        h.u = hits[i*10 + 7]; h.v = hits[i*10 + 8];
+        const double idf = hits[i*10 + 6];
         uint32_t c = 0;
         if (idf >= 0.0 && idf < static_cast<double>(sc.n_prims)) {
-            c = shade<false>(sc, h, static_cast<int32_t>(idf), view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            const rt_mat_rec m = sc.mats[static_cast<int32_t>(idf)];
+            // a texture is only consulted when the Hit carries surface coordinates (mesh.cpp:23)
+            const uint32_t alb = (hits[i*10 + 9] != 0.0) ? albedo_at(sc, m, h.u, h.v) : solid_albedo(m);
+            c = shade_material<false>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
         } else if (idf == -2.0) {
             // a hit that names no primitive: white, non-metallic, roughness 0.5 (raytracer.cpp:204-208, 250-254, 268-272)
             rt_mat_rec m;
             m.metallic = 0.0; m.roughness = 0.5; m.ior = 1.5; m.albedo[0] = 255; m.albedo[1] = 255; m.albedo[2] = 255;
-            c = shade_material<false>(sc, h, m, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            m.tex = -1;
+            c = shade_material<false>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
         }
         rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
     }
@@ -920,7 +948,8 @@ __global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, FrameBufs f
         double lighting = first ? 0.0 : fb.lighting[i];
         for (uint32_t j = 0; j < n_batch; ++j) lighting += fb.contrib[static_cast<size_t>(j) * fb.n + i];
         if (!last) { fb.lighting[i] = lighting; return; }
-        local = finish_shade(sc.mats[id], lighting);
+        const rt_mat_rec m0 = sc.mats[id];
+        local = finish_shade(m0, fb.albedo ? fb.albedo[i] : solid_albedo(m0), lighting);
     } else if (!last) return;
     lv.local[static_cast<size_t>(level) * fb.n + i] = local;
     lv.last[i] = static_cast<uint8_t>(level);
@@ -934,18 +963,18 @@ __global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, FrameBufs f
         const double vx = -dx * inv_len, vy = -dy * inv_len, vz = -dz * inv_len;
         const double ct = nx*vx + ny*vy + nz*vz;
         const double cos_theta = (0.0 < ct) ? ct : 0.0;
+        const uint32_t alb = fb.albedo ? fb.albedo[i] : solid_albedo(m);
         double f0;
         if (m.metallic <= 0.0) { const double r0 = (m.ior - 1.0) / (m.ior + 1.0); f0 = clampd(r0 * r0, 0.0, 1.0); }
         else {
-            const double avg = (static_cast<double>(m.albedo[0]) + static_cast<double>(m.albedo[1]) + static_cast<double>(m.albedo[2])) / (3.0 * 255.0);
+            const double avg = (static_cast<double>(alb & 255u) + static_cast<double>((alb >> 8) & 255u) + static_cast<double>((alb >> 16) & 255u)) / (3.0 * 255.0);
             f0 = clampd(avg, 0.0, 1.0);
         }
         const double fr = f0 + (1.0 - f0) * pow(1.0 - cos_theta, 5.0);
         if (!(fr <= 0.0 || fr < min_scatter_intensity)) {
             go = true;
             lv.fr[static_cast<size_t>(level) * fb.n + i] = fr;
-            lv.tint[static_cast<size_t>(level) * fb.n + i] = static_cast<uint32_t>(m.albedo[0]) | static_cast<uint32_t>(m.albedo[1]) << 8
-                                                           | static_cast<uint32_t>(m.albedo[2]) << 16 | (m.metallic > 0.0 ? 1u << 24 : 0u);
+            lv.tint[static_cast<size_t>(level) * fb.n + i] = alb | (m.metallic > 0.0 ? 1u << 24 : 0u);
             // mirror direction exactly as the intersectors leave it in the Hit (mesh.cpp:236-247 and siblings)
             const double ddn = dx*nx + dy*ny + dz*nz;
             const double tx = dx - 2.0 * ddn * nx, ty = dy - 2.0 * ddn * ny, tz = dz - 2.0 * ddn * nz;
@@ -1030,16 +1059,20 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
     const FrameBufs none{};
     const uint32_t n_rays = n_tiles * 64u;
     const dim3 grid(n_waves), block(64);
-    if (fb && fb->ray) {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, 2>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<0, false, 2>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
-    } else if (fb) {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, 1>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<0, false, 1>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, *fb, ctr, queue, refill_min);
-    } else {
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, 0>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<0, false, 0>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, none, ctr, queue, refill_min);
+    const int variant = !fb ? 0 : (1 | (fb->ray ? 2 : 0) | (fb->albedo ? 4 : 0));
+#define RT_LAUNCH_PRIMARY(R, FB)                                                                                                         \
+    do {                                                                                                                                 \
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, R>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min);  \
+        else          hipLaunchKernelGGL((k_rays<0, false, R>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
+    } while (0)
+    switch (variant) {
+        case 0: RT_LAUNCH_PRIMARY(0, none); break;
+        case 1: RT_LAUNCH_PRIMARY(1, *fb); break;
+        case 3: RT_LAUNCH_PRIMARY(3, *fb); break;
+        case 5: RT_LAUNCH_PRIMARY(5, *fb); break;
+        default: RT_LAUNCH_PRIMARY(7, *fb); break;
     }
+#undef RT_LAUNCH_PRIMARY
     return hipGetLastError();
 }
 

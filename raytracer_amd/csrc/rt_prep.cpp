@@ -150,6 +150,7 @@ void rt_make_material(const rt_prim_desc& p, rt_mat_rec& m) {
     std::memset(&m, 0, sizeof(m));
     m.metallic = p.metallic; m.roughness = p.roughness; m.ior = p.ior;
     for (int k = 0; k < 3; ++k) m.albedo[k] = unit_to_u8(p.albedo[k]);
+    m.tex = -1;
 }
 
 // The reference's own compute_aabb, type by type (mesh.cpp:288-309, 517-538, 683-701, 922-930).  A plane

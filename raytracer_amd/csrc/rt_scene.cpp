@@ -22,6 +22,7 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
     for (uint64_t i = 0; i < n; ++i) {
         const rt_prim_desc& p = s->prims[i];
         rt_make_material(p, s->mats[i]);
+        if (i < s->prim_tex.size()) s->mats[i].tex = s->prim_tex[i];
         if (p.kind >= 0 && p.kind < 8) ++info.n_by_kind[p.kind];
         rt_prim_rec rec; rt_box64 box;
         switch (rt_make_record(p, static_cast<uint32_t>(i), rec, box)) {

@@ -22,6 +22,11 @@ struct rt_scene {
     std::vector<uint32_t>     slot_prim;             // slot -> id (bounded, BVH order; loose ones appended)
     uint64_t n_slots = 0, n_loose = 0;
     rt_scene_info info{};
+    // albedo textures (Mesh::setAlbedoTexture, mesh.h:47): pool of texels, one table entry per texture, and the
+    // texture of each primitive (-1 = none)
+    std::vector<uint8_t>    texels;
+    std::vector<rt_tex_rec> tex_table;
+    std::vector<int32_t>    prim_tex;
 };
 
 // rt_prep.cpp
@@ -37,11 +42,14 @@ void rt_gamma_table(uint8_t lut[256]);
 struct rt_bvh_result { std::vector<rt_node32> nodes; std::vector<uint32_t> order; uint32_t depth = 0; };
 void rt_build_bvh(const std::vector<rt_box64>& boxes, uint32_t max_leaf, uint32_t bins, rt_bvh_result& out);
 
-// rt_json.cpp
+// rt_json.cpp; tex_paths receives one entry per primitive ("" = no albedo_texture_ppm given)
 int rt_parse_scene_file(const char* path, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
-                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err);
+                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::vector<std::string>& tex_paths, std::string& err);
 int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,
-                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::string& err);
+                        std::vector<std::pair<std::string, rt_camera>>& cameras, std::vector<std::string>& tex_paths, std::string& err);
+// rt_image.cpp: Image::loadFromFile (utils.cpp:212-250); false on any error
+bool rt_load_ppm(const char* path, int32_t& width, int32_t& height, int32_t& maxval, std::vector<uint8_t>& rgb, std::string& err);
+void rt_scene_attach_textures(rt_scene* s, const std::vector<std::string>& tex_paths);
 int rt_parse_camera_file(const char* path, const char* camera_id, rt_camera* out, std::string& err);
 
 // rt_scene.cpp

@@ -243,18 +243,76 @@ def _v(x, y, z):
     return {"x": float(x), "y": float(y), "z": float(z)}
 
 
-def scene_to_json(prims, lights, cameras, path=None):
+def make_texture(seed, width, height, maxval=255):
+    """Deterministic (height, width, 3) uint8 texture with samples in [0, maxval]."""
+    rng = SplitMix64(seed)
+    u = rng.uniform(width * height * 3).reshape(height, width, 3)
+    y, x = np.mgrid[0:height, 0:width]
+    checker = (((x // 2) + (y // 2)) % 2)[..., None]
+    return np.clip(np.floor((0.25 + 0.5 * checker + 0.25 * u) * (maxval + 1)), 0, maxval).astype(np.uint8)
+
+
+def write_ppm(path, pixels, maxval=255, ascii_format=False, comments=False):
+    """P6 (or P3) file as the reference's Image reads it: samples are stored as they are, never rescaled."""
+    h, w, _ = pixels.shape
+    head = "%s\n%s%d %d\n%s%d\n" % ("P3" if ascii_format else "P6", "# made by scenes.write_ppm\n" if comments else "",
+                                  w, h, "# maxval next\n" if comments else "", maxval)
+    with open(path, "wb") as f:
+        f.write(head.encode())
+        if ascii_format:
+            rows = [" ".join(str(int(v)) for v in row.reshape(-1)) for row in pixels]
+            f.write(("\n".join(rows) + "\n").encode())
+        else:
+            f.write(np.ascontiguousarray(pixels, dtype=np.uint8).tobytes())
+
+
+def textured_scene(directory):
+    """Seeded scene of all four reference kinds where most primitives carry an albedo texture.  Writes the texture
+    files into `directory` and returns (prims, lights, camera dict, texture arrays, texture index per primitive,
+    texture path per primitive).  Two primitives name files that cannot be loaded and keep their solid colour."""
+    import os
+    prims, lights, cam = random_scene(36, 77, lights=2)
+    cam = dict(cam, res=(320, 180))
+    prims["metallic"][::3] = 0.6                        # textured metals: the tint and F0 paths
+    specs = [(8, 8, 255, False, False), (5, 3, 100, True, True), (1, 1, 255, False, False), (64, 32, 255, False, True), (2, 2, 255, True, False)]
+    textures, files = [], []
+    for k, (w, h, mv, asc, com) in enumerate(specs):
+        t = make_texture(1000 + k, w, h, mv)
+        p = os.path.join(directory, "tex%d.ppm" % k)
+        write_ppm(p, t, mv, asc, com)
+        textures.append(t); files.append(p)
+    broken = os.path.join(directory, "broken.ppm")
+    with open(broken, "wb") as f:
+        f.write(b"P6\n4 4\n255\nshort")
+    prim_tex = np.full(len(prims), -1, dtype=np.int32)
+    paths = [""] * len(prims)
+    for i in range(len(prims)):
+        if i % 6 == 5:
+            continue                                    # solid colour
+        if i == 7:
+            paths[i] = os.path.join(directory, "does_not_exist.ppm")
+        elif i == 13:
+            paths[i] = broken
+        else:
+            prim_tex[i] = i % len(specs)
+            paths[i] = files[prim_tex[i]]
+    return prims, lights, cam, textures, prim_tex, paths
+
+
+def scene_to_json(prims, lights, cameras, path=None, texture_paths=None):
     """Serialise reference-kind primitives (no triangles) to the scene format the reference loads.
     repr()-style floats round-trip exactly, so the loaded scene equals the in-memory one bit for bit."""
     mesh = {"Cube": {}, "Sphere": {}, "Plane": {}, "Cylinder": {}}
     next_id = 1
-    for p in prims:
+    for index, p in enumerate(prims):
         k = int(p["kind"])
         if k == TRIANGLE:
             raise ValueError("the reference scene format has no triangle")
         q = p["q"]
         mat = {"alpha": float(p["alpha"]), "metallic": float(p["metallic"]), "roughness": float(p["roughness"]),
                "ior": float(p["ior"]), "albedo": _v(*p["albedo"])}
+        if texture_paths is not None and texture_paths[index]:
+            mat["albedo_texture_ppm"] = texture_paths[index]
         if k in (CUBE, CYLINDER):
             obj = {"translation": _v(*q[0:3]), "rotation": {"roll": float(q[3]), "pitch": float(q[4]), "yaw": float(q[5])},
                    "scale": _v(*q[6:9]), "material": mat}

@@ -165,3 +165,17 @@ def test_render_driver_multi_sample_and_time_driver(tmp_path):
     times = [float(x) for x in lines[1:4] + lines[5:8]]
     assert all(0.0 < t < 1.0 for t in times)
     assert "Mean (accelerated):" in r.stdout
+
+
+@pytest.mark.gpu
+def test_render_driver_with_textures(tmp_path):
+    from raytracer_amd import scenes as S
+    g = np.load(os.path.join(GOLDEN, "textured.npz"))
+    prims, lights, camd, textures, prim_tex, paths = S.textured_scene(str(tmp_path))
+    jp = str(tmp_path / "scene.json")
+    S.scene_to_json(prims, lights, {"3": camd}, jp, texture_paths=paths)
+    out = str(tmp_path / "frame.ppm")
+    r = run([exe("render_driver"), jp, "3", out])
+    assert r.returncode == 0, r.stderr
+    diff = np.abs(read_ppm(out).astype(np.int16) - g["render2"].astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).any(-1).mean() <= 1e-3

@@ -288,3 +288,43 @@ def test_library_aabbs_of_constructed_primitives(kind):
         got = np.asarray(capi.prim_aabb(prim[0])).reshape(-1)
         want = np.asarray(g[k + "_aabb"][t], dtype=np.float64).reshape(-1)
         assert np.array_equal(got.view(np.int64), want.view(np.int64)), (k, t)
+
+
+def test_textures_from_the_scene_file(tmp_path):
+    """albedo_texture_ppm: P6 and P3 files (comments, maxval 100) are read as the reference's Image reads them; files
+    that are missing or cut short leave the primitive with its solid colour (mesh.cpp:105-110)."""
+    prims, lights, camd, textures, prim_tex, paths = S.textured_scene(str(tmp_path))
+    jp = str(tmp_path / "scene.json")
+    S.scene_to_json(prims, lights, {"3": camd}, jp, texture_paths=paths)
+    sc = capi.Scene.load_json(jp)
+    assert sc.info().n_prims == len(prims)
+    for i in range(len(prims)):
+        t = sc.texture(i)
+        if prim_tex[i] < 0:
+            assert t is None, i
+        else:
+            assert np.array_equal(t, textures[prim_tex[i]]), i
+    px, maxval = capi.read_ppm(paths[1])            # index 1 -> tex1: ASCII, comments, maxval 100
+    assert maxval == 100 and np.array_equal(px, textures[1]) and px.max() <= 100
+    with pytest.raises(capi.RtError) as e:
+        capi.read_ppm(str(tmp_path / "does_not_exist.ppm"))
+    assert e.value.status == -2
+    with pytest.raises(capi.RtError) as e:
+        capi.read_ppm(str(tmp_path / "broken.ppm"))
+    assert e.value.status == -8 and "Unexpected EOF" in str(e.value)
+    bad = tmp_path / "bad.ppm"
+    for content, msg in ((b"P5\n1 1\n255\n\x00", "Unsupported PPM format"), (b"P6\n0 1\n255\n", "Invalid PPM header"),
+                         (b"P6\n1 1\n70000\n", "max value"), (b"P3\n1 1\n9\n1 2 10\n", "out of range")):
+        bad.write_bytes(content)
+        with pytest.raises(capi.RtError) as e:
+            capi.read_ppm(str(bad))
+        assert msg in str(e.value), (content, str(e.value))
+    # the same textures attached to a scene built in memory
+    sc2 = capi.Scene.create(prims, lights)
+    assert sc2.texture(0) is None
+    sc2.set_textures(textures, prim_tex)
+    for i in range(len(prims)):
+        t = sc2.texture(i)
+        assert (t is None) if prim_tex[i] < 0 else np.array_equal(t, textures[prim_tex[i]])
+    with pytest.raises(capi.RtError):
+        sc2.set_textures(textures, np.full(len(prims), len(textures), dtype=np.int32))
