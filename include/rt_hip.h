@@ -69,7 +69,7 @@ typedef struct rt_node32 { float lo[3]; uint32_t first; float hi[3]; uint32_t co
 
 typedef struct rt_build_opts {
     uint32_t max_leaf;        /* primitives per leaf, 1..8 (0 = default 1) */
-    uint32_t sah_bins;        /* 4..32 (0 = default 16) */
+    uint32_t sah_bins;        /* 4..32 (0 = default 32) */
     uint32_t reserved[6];
 } rt_build_opts;
 

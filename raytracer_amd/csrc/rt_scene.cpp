@@ -7,7 +7,7 @@
 
 int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
     const uint32_t max_leaf = (opts && opts->max_leaf) ? opts->max_leaf : 1;
-    const uint32_t bins = (opts && opts->sah_bins) ? opts->sah_bins : 16;
+    const uint32_t bins = (opts && opts->sah_bins) ? opts->sah_bins : 32;
     const uint64_t n = s->prims.size();
     if (n >= (1ull << 28)) return RT_ERR_LIMIT;      // node references keep 28 bits for a slot / child-pair index
 
