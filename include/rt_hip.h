@@ -41,7 +41,8 @@ enum { RT_CUBE = 0, RT_PLANE = 1, RT_CYLINDER = 2, RT_SPHERE = 3, RT_TRIANGLE = 
  *   cube / cylinder: q[0..2] translation, q[3..5] roll,pitch,yaw (R = Rz Ry Rx), q[6..8] scale
  *   sphere: q[0..2] location, q[3..5] scale      plane: q[0..11] four corners (corner 2 is ignored by
  *   the intersector, as in mesh.cpp:799-804)     triangle: q[0..8] three corners
- * and the material block of mesh.h:52-59.  reserved != 0 on a plane = fewer than four corners were given. */
+ * and the material block of mesh.h:52-59.  reserved on a plane: 0 = four corners; 1..3 = only that many were given
+ * (the plane is kept, spans those corners and is never hit, mesh.cpp:796, 922-930); any other value = no corners. */
 typedef struct rt_prim_desc {
     int32_t kind;
     int32_t reserved;

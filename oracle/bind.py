@@ -378,7 +378,7 @@ def load_scene_json(path):
                 if len(flat) < 12:
                     # fewer than four corners: the reference keeps the primitive but it never intersects
                     flat += [0.0] * (12 - len(flat))
-                    p["reserved"] = 1
+                    p["reserved"] = len(corners) if len(corners) else -1
                 p["q"][:12] = flat
             _material(p, obj)
             rows.append(p)

@@ -1,0 +1,191 @@
+"""Scene-file corpus for the loader, with what the REAL reference loader makes of every document.
+
+    python oracle/make_loader_fuzz.py        (development container only: needs oracle/_ref/libref_rt.so)
+
+Writes tests/golden/loader_fuzz.npz: the documents themselves plus, per document, the reference's primitive count and
+AABBs, its primary rays at five pixels per queried camera (RayTracer's loader and the stand-alone camera reader), and
+ids / distances / linear colours for a fixed fan of rays (which pins lights and materials).  Documents avoid the one
+input class where the reference does not return at all (a malformed number makes std::stod throw)."""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import bind                      # noqa: E402
+from raytracer_amd import scenes as S        # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def v(x, y, z):
+    return {"x": x, "y": y, "z": z}
+
+
+CAM = {"location": v(0.5, -9.0, 3.0), "direction": v(0.0, 0.9, -0.3), "focal_length": 35.0, "sensor_width": 36.0,
+       "sensor_height": 24.0, "film_resolution": {"x": 48, "y": 27}}
+LIGHTS = {"POINT": {"90": {"location": v(3.0, -4.0, 6.0), "radiant_intensity": 30.0},
+                    "91": {"location": v(-5.0, -2.0, 4.0), "radiant_intensity": 12.5}}}
+CUBE = {"translation": v(0.5, 0.0, 0.6), "rotation": {"roll": 0.3, "pitch": -0.2, "yaw": 1.1}, "scale": v(0.8, 0.6, 0.5),
+        "material": {"alpha": 1.0, "metallic": 0.3, "roughness": 0.4, "ior": 1.45, "albedo": v(0.8, 0.3, 0.2)}}
+SPHERE = {"location": v(-1.5, 0.5, 0.8), "scale": v(0.9, 0.7, 0.8), "material": {"metallic": 0.0, "roughness": 0.2, "albedo": v(0.2, 0.7, 0.9)}}
+CYL = {"translation": v(2.4, 0.8, 0.9), "rotation": {"roll": 1.2, "pitch": 0.4, "yaw": -0.7}, "scale": v(0.5, 0.5, 0.9)}
+PLANE = {"corners": [v(-6, -6, 0), v(6, -6, 0), v(6, 6, 0), v(-6, 6, 0)], "material": {"roughness": 0.9, "albedo": v(0.6, 0.6, 0.55)}}
+
+
+def base():
+    return {"MESH": {"Cube": {"1": json.loads(json.dumps(CUBE))}, "Sphere": {"2": json.loads(json.dumps(SPHERE))},
+                     "Cylinder": {"3": json.loads(json.dumps(CYL))}, "Plane": {"4": json.loads(json.dumps(PLANE))}},
+            "CAMERA": {"PERSP": {"7": json.loads(json.dumps(CAM))}}, "LIGHT": json.loads(json.dumps(LIGHTS))}
+
+
+def documents():
+    """(name, text, camera ids to query)"""
+    docs = []
+
+    def add(name, doc, cams=("7",), **dump):
+        docs.append((name, doc if isinstance(doc, str) else json.dumps(doc, **dump), list(cams)))
+
+    add("baseline", base(), indent=2)
+    add("compact_no_whitespace", base(), separators=(",", ":"))
+    add("tabs_and_newlines", json.dumps(base(), indent="\t").replace(": ", "\t:\n\t"))
+    d = base(); d = {"LIGHT": d["LIGHT"], "CAMERA": d["CAMERA"], "MESH": {k: d["MESH"][k] for k in ("Plane", "Cylinder", "Sphere", "Cube")}}
+    add("sections_and_classes_reordered", d, indent=1)
+    d = base(); c = d["MESH"]["Cube"]["1"]
+    d["MESH"]["Cube"]["1"] = {"material": c["material"], "scale": {"z": 0.5, "x": 0.8, "y": 0.6}, "rotation": {"yaw": 1.1, "roll": 0.3, "pitch": -0.2},
+                              "translation": {"y": 0.0, "z": 0.6, "x": 0.5}}
+    add("members_reordered", d, indent=1)
+    text = json.dumps(base(), indent=1)
+    text = text.replace("0.8", "8e-1").replace("0.6", "+0.6").replace("1.1", "1.1E0").replace("30.0", "3e1").replace("-0.2", "-2.0e-1")
+    add("exponents_and_signs", text)
+    d = base(); del d["MESH"]["Cube"]["1"]["scale"]; del d["MESH"]["Cube"]["1"]["rotation"]; del d["MESH"]["Sphere"]["2"]["scale"]
+    del d["MESH"]["Cylinder"]["3"]["translation"]
+    add("defaults_for_missing_geometry", d, indent=1)
+    d = base(); del d["MESH"]["Cube"]["1"]["material"]; d["MESH"]["Sphere"]["2"]["material"] = {"alpha": 0.5}
+    d["MESH"]["Plane"]["4"]["material"] = {"albedo": {"x": 0.1, "y": 0.2}}          # incomplete albedo: default kept
+    add("defaults_for_missing_material", d, indent=1)
+    d = base(); d["MESH"]["Cube"]["1"]["rotation"] = {"roll": 0.3}
+    add("partial_rotation", d, indent=1)
+    d = base(); d["MESH"]["Cube"] = {"10": CUBE, "2": dict(CUBE, translation=v(-3, 2, 0.6)), "33": dict(CUBE, translation=v(3.5, -1, 0.5), scale=v(0.3, 0.3, 0.3))}
+    add("ids_not_in_numeric_order", d, indent=1)
+    d = base(); d["MESH"]["Cube"]["abc"] = dict(CUBE, translation=v(9, 9, 9)); d["MESH"]["Cube"]["1x"] = dict(CUBE, translation=v(8, 8, 8))
+    add("non_numeric_ids_are_skipped", d, indent=1)
+    d = base(); d["MESH"]["Plane"]["5"] = {"corners": [v(0, 0, 2), v(1, 0, 2), v(1, 1, 2)]}
+    d["MESH"]["Plane"]["6"] = {"corners": [v(-1, -1, 3), v(1, -1, 3), v(1, 1, 3), v(-1, 1, 3), v(0, 0, 9)]}
+    add("planes_with_three_and_five_corners", d, indent=1)
+    d = base(); d["MESH"]["Plane"]["5"] = {"corners": [v(0, 0, 1), v(0, 0, 1), v(1, 1, 1), v(0, 1, 1)]}      # degenerate edge
+    add("degenerate_plane", d, indent=1)
+    d = base(); d["MESH"]["Plane"]["5"] = {"material": {"roughness": 0.1}}                                   # no corners at all
+    add("plane_without_corners", d, indent=1)
+    d = base(); d["MESH"]["Cube"]["1"]["scale"] = v(0.0, 0.6, 0.5); d["MESH"]["Sphere"]["2"]["scale"] = v(0.9, 0.0, 0.8)
+    add("zero_scales", d, indent=1)
+    d = base(); d["MESH"]["Sphere"]["2"]["scale"] = v(-0.9, 0.7, -0.8); d["MESH"]["Cube"]["1"]["scale"] = v(0.8, -0.6, 0.5)
+    add("negative_scales", d, indent=1)
+    d = base(); d["MESH"] = {"Cube": {}, "Sphere": {}}
+    add("empty_classes", d, indent=1)
+    d = base(); del d["MESH"]
+    add("no_mesh_section", d, indent=1)
+    d = base(); del d["LIGHT"]
+    add("no_lights", d, indent=1)
+    d = base(); d["LIGHT"]["POINT"]["92"] = {"location": v(0, 0, 9)}; d["LIGHT"]["POINT"]["93"] = {"radiant_intensity": 99.0}
+    add("light_defaults_and_light_without_location", d, indent=1)
+    d = base(); d["CAMERA"]["PERSP"]["8"] = dict(CAM, location=v(6, -6, 5), direction=v(-0.6, 0.6, -0.45), up=v(0.1, 0.2, 0.97))
+    d["CAMERA"]["PERSP"]["9"] = {"location": v(0, 0, 12), "direction": v(0, 0, -1)}                          # straight down, all defaults
+    add("several_cameras_up_vector_and_defaults", d, cams=("7", "8", "9", "10"), indent=1)
+    d = base(); d["CAMERA"]["PERSP"]["7"]["film_resolution"] = {"x": 64.0, "y": 36.0}
+    add("film_resolution_with_fraction", d, indent=1)
+    d = base(); d["CAMERA"]["PERSP"]["7"]["film_resolution"] = {"y": 27, "x": 48}
+    add("film_resolution_y_before_x", d, indent=1)
+    d = base(); d["CAMERA"]["PERSP"]["7"]["sensor_width"] = 24.0; d["CAMERA"]["PERSP"]["7"]["sensor_height"] = 36.0
+    add("portrait_sensor", d, indent=1)
+    d = base(); d["CAMERA"]["PERSP"]["7"]["direction"] = v(0, 0, 0)
+    add("zero_camera_direction", d, indent=1)
+    d = base(); d["MESH"]["Cube"]["1"]["material"]["albedo_texture_ppm"] = "C:\\Users\\x\\tex}{.ppm"
+    d["MESH"]["Cube"]["1"]["note"] = 'a "quoted" {brace'
+    add("strings_with_braces_and_quotes", d, indent=1)
+    d = base(); d["MESH"]["Cube"]["1"]["material"] = {"extra": {"alpha": 0.25, "metallic": 0.9}, "roughness": 0.15}
+    add("material_values_nested_deeper", d, indent=1)
+    d = base(); d["MESH"]["Sphere"]["2"]["location"] = {"x": 1, "y": 2, "z": 1, "w": 5}
+    add("integers_and_extra_members", d, indent=1)
+    text = json.dumps(base(), indent=1).replace('"roughness": 0.4', '"roughness": 0.4, "roughness": 0.05')
+    add("duplicate_key_first_wins", text)
+    d = base(); d["MESH"]["Cube"]["1"]["material"]["albedo"] = v(1.7, -0.4, 0.5)
+    add("albedo_outside_unit_range", d, indent=1)
+    d = base(); d["MESH"]["Cube"]["1"]["material"].update(metallic=1.5, roughness=0.0)
+    add("metallic_above_one_roughness_zero", d, indent=1)
+    add("empty_document", "{}")
+    add("not_json_at_all", "this is not a scene")
+    rng = S.SplitMix64(4242)
+    for k in range(6):                              # seeded mixed scenes, varying whitespace
+        prims, lights, cam = S.random_scene(10 + 3 * k, 500 + k, lights=1 + k % 3)
+        text = S.scene_to_json(prims, lights, {"7": dict(cam, res=(48, 27))})
+        if k % 2:
+            text = json.dumps(json.loads(text), separators=(",", ":"))
+        add("seeded_%d" % k, text)
+    _ = rng
+    return docs
+
+
+def ray_fan():
+    """Fixed rays from a ring around the scene towards points near the origin."""
+    rng = S.SplitMix64(99)
+    u = rng.uniform(96 * 5).reshape(96, 5)
+    ang = 2 * np.pi * u[:, 0]
+    o = np.stack([9 * np.cos(ang), 9 * np.sin(ang), 0.5 + 6 * u[:, 1]], axis=1)
+    t = np.stack([(u[:, 2] - 0.5) * 6, (u[:, 3] - 0.5) * 6, u[:, 4] * 1.5], axis=1)
+    return np.concatenate([o, t - o], axis=1)
+
+
+PIXELS = np.array([[0.5, 0.5], [47.5, 0.5], [24.5, 13.5], [0.5, 26.5], [47.5, 26.5]])
+
+
+def main():
+    R = bind.Ref()
+    rays = ray_fan()
+    out = {"rays": rays, "pixels": PIXELS}
+    names, texts = [], []
+    with tempfile.TemporaryDirectory() as td:
+        for k, (name, text, cams) in enumerate(documents()):
+            path = os.path.join(td, "d%d.json" % k)
+            with open(path, "w") as f:
+                f.write(text)
+            names.append(name); texts.append(text)
+            h = R.load(path)
+            assert h, name
+            n = R.num_meshes(h)
+            out["n_%d" % k] = n
+            out["aabbs_%d" % k] = R.aabbs(h).reshape(-1, 6) if n else np.zeros((0, 6))
+            hits = R.trace_rays(h, rays)
+            out["ids_%d" % k] = hits["id"].astype(np.int32)
+            out["dist_%d" % k] = hits["dist"]
+            out["rgb_%d" % k] = R.shade_rays(h, rays)
+            out["cams_%d" % k] = np.array(cams)
+            for cid in cams:
+                pr = R.primary_rays(h, cid)
+                out["count_%d_%s" % (k, cid)] = len(pr)
+                if len(pr):
+                    # the reference hands back every pixel; keep the five probe pixels of a 48-wide frame when it is one
+                    W = 48 if len(pr) == 48 * 27 else (1920 if len(pr) == 1920 * 1080 else 0)
+                    out["width_%d_%s" % (k, cid)] = W
+                    if W:
+                        scale = W / 48.0
+                        idx = [int((y * (1080 / 27.0 if W == 1920 else 1.0))) * W + int(x * scale) for x, y in PIXELS]
+                        out["primary_%d_%s" % (k, cid)] = pr[idx]
+                        out["primary_px_%d_%s" % (k, cid)] = np.array([[i % W + 0.5, i // W + 0.5] for i in idx])
+                alone = R.camera_rays(path, cid, PIXELS)
+                out["alone_ok_%d_%s" % (k, cid)] = alone is not None
+                if alone is not None:
+                    out["alone_%d_%s" % (k, cid)] = alone
+            R.free(h)
+            print("%-44s prims %2d  hits %2d" % (name, n, int((hits["id"] >= 0).sum())))
+    out["names"] = np.array(names)
+    out["texts"] = np.array(texts)
+    np.savez_compressed(os.path.join(GOLD, "loader_fuzz.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

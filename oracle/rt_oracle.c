@@ -331,7 +331,10 @@ void rto_aabb(const rto_prim* prim, double mn[3], double mx[3]) {
     mx[0] = mx[1] = mx[2] = -RTO_INF;
     const double* q = prim->q;
     if (prim->kind == RTO_PLANE || prim->kind == RTO_TRIANGLE) {
-        const int nc = (prim->kind == RTO_PLANE) ? 4 : 3;
+        /* reserved on a plane: 0 = four corners, 1..3 = only that many were given, anything else = none */
+        int nc = 3;
+        if (prim->kind == RTO_PLANE) nc = (prim->reserved == 0) ? 4 : ((prim->reserved > 0 && prim->reserved < 4) ? prim->reserved : 0);
+        if (nc == 0) { mn[0] = mn[1] = mn[2] = 0.0; mx[0] = mx[1] = mx[2] = 0.0; return; }
         for (int c = 0; c < nc; ++c)
             for (int k = 0; k < 3; ++k) {
                 const double x = q[c*3 + k];

@@ -410,12 +410,12 @@ Sphere::Sphere(const Float3& c, const Float3& s) {
     m_desc.q[0] = c.x; m_desc.q[1] = c.y; m_desc.q[2] = c.z; m_desc.q[3] = s.x; m_desc.q[4] = s.y; m_desc.q[5] = s.z;
 }
 
-Plane::Plane() { m_desc = blank_desc(RT_PLANE); m_desc.reserved = 1; }
+Plane::Plane() { m_desc = blank_desc(RT_PLANE); m_desc.reserved = -1; }
 Plane::Plane(const std::vector<Float3>& corners) {
     m_desc = blank_desc(RT_PLANE);
     m_n_corners = static_cast<int>(std::min<size_t>(corners.size(), 4));
     for (int k = 0; k < m_n_corners; ++k) { m_desc.q[3*k] = corners[k].x; m_desc.q[3*k + 1] = corners[k].y; m_desc.q[3*k + 2] = corners[k].z; }
-    if (corners.size() < 4) m_desc.reserved = 1;         // never hit (mesh.cpp:796)
+    if (corners.size() < 4) m_desc.reserved = corners.empty() ? -1 : static_cast<int32_t>(corners.size());   // never hit (mesh.cpp:796)
 }
 
 // mesh.cpp:922-930: min / max over the stored corners; no corners leaves the outputs untouched at zero
@@ -491,7 +491,7 @@ static Plane make_plane(const rt_prim_desc& d) {
     std::vector<Float3> c;
     // a plane read with fewer than four corners keeps reserved != 0; its missing corners are zero and never used
     for (int k = 0; k < 4; ++k) c.push_back(Float3{ d.q[3*k], d.q[3*k + 1], d.q[3*k + 2] });
-    if (d.reserved) c.resize(3);
+    if (d.reserved) c.resize(d.reserved > 0 && d.reserved < 4 ? d.reserved : 0);
     return Plane(c);
 }
 static Triangle make_triangle(const rt_prim_desc& d) {

@@ -285,7 +285,7 @@ int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>&
                 if (corners->type == Node::Array) for (const auto& it : corners->items) take(*it);
                 else for (const Member& m : corners->members) take(*m.second);
                 if (n == 0) return;
-                if (n < 4) d.reserved = 1;            // kept, never hit (mesh.cpp:796)
+                if (n < 4) d.reserved = n;            // kept with the corners it has, never hit (mesh.cpp:796)
                 read_material(o, d);
                 prims.push_back(d);
                 tex_paths.push_back(g_texture_path);

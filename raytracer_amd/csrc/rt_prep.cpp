@@ -159,8 +159,11 @@ void rt_reference_aabb(const rt_prim_desc& p, double out6[6]) {
     rt_box64 b; box_reset(b);
     const double* q = p.q;
     if (p.kind == RT_PLANE || p.kind == RT_TRIANGLE) {
-        const int nc = (p.kind == RT_PLANE) ? 4 : 3;
+        // a plane given fewer than four corners spans only those (mesh.cpp:922-930); none at all gives a zero box
+        int nc = 3;
+        if (p.kind == RT_PLANE) nc = (p.reserved == 0) ? 4 : ((p.reserved > 0 && p.reserved < 4) ? p.reserved : 0);
         for (int c = 0; c < nc; ++c) box_add(b, q + 3*c);
+        if (nc == 0) { for (int k = 0; k < 6; ++k) out6[k] = 0.0; return; }
     } else if (p.kind == RT_SPHERE) {
         for (int dx = -1; dx <= 1; dx += 2) for (int dy = -1; dy <= 1; dy += 2) for (int dz = -1; dz <= 1; dz += 2) {
             const double pw[3] = { q[0] + dx * q[3], q[1] + dy * q[4], q[2] + dz * q[5] };
