@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 #include "rt_internal.h"
 
+#ifndef RT_STACK_LDS
 #define RT_STACK_LDS 16            // traversal stack entries per lane kept in LDS (8 bytes each); deeper ones go private
+#endif
 #define RT_CTR_SHARDS 64           // counter replicas, one cache line each, summed on read
 #define RT_CTR_STRIDE 16           // 64-bit words between replicas (128 bytes)
 #define RT_LIGHT_BATCH 8           // lights per shadow launch (bounds the contribution planes)
