@@ -124,3 +124,59 @@ def test_config2_cube_field_as_triangles(ctx, oracle):
     both = (cid >= 0) & ~mismatch
     rel = np.abs(tdist[both] - cdist[both]) / cdist[both]
     assert rel.max() < 1e-6
+
+
+def test_mirror_bounces_on_a_dense_field(ctx, oracle):
+    """The level-by-level bounce pipeline where secondary rays are incoherent: 30k primitives, two bounces, against the
+    brute-force restatement of trace_ray_recursive on a 24x16 window in the middle of the field, plus the partition
+    property on the whole frame."""
+    import torch
+    prims = S.mixed_field(n_side=150, seed=0x100000)
+    prims["metallic"][::4] = 0.7
+    prims["roughness"][::5] = 0.05
+    lights = S.mixed_field_lights(half_extent=75.0, height=18.0, intensity=90.0)
+    W, H = 640, 360
+    cam = capi.make_camera(**S.mixed_field_camera(half_extent=75.0, res=(W, H)))
+    sc = capi.Scene.create(prims, lights)
+    ctx.upload(sc)
+    ctx.reset_counters()
+    rgb = ctx.render(cam, max_scatters=2)
+    c = ctx.counters()
+    assert c["bounce_rays"] > c["primary_hits"]            # dielectrics always reflect a little: two levels of bounces
+    rect = (300, 200, 24, 16)
+    want, _, _ = oracle.render(oracle.scene(prims, lights), ocamera(cam), rect=rect, max_scatters=2, threads=8)
+    got = rgb[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).any(-1).mean() < 0.02
+    # min_scatter_intensity cuts weak bounces: between the no-bounce and the full frame
+    strong = ctx.render(cam, max_scatters=2, min_scatter_intensity=0.5)
+    assert not np.array_equal(strong, rgb) and not np.array_equal(strong, ctx.render(cam, max_scatters=0))
+    tiling = capi.Tiling(W, H, 48, 5)
+    per = capi.tiles_per_rank(tiling) * 48 * 48 * 3
+    gathered = torch.empty(5 * per, dtype=torch.uint8, device="cuda")
+    for r in range(5):
+        ctx.render_tiles_dev(cam, tiling, r, gathered.data_ptr() + r * per, 2, 0.0)
+    frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
+    ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), rgb)
+
+
+def test_config4_8k_frame(ctx, oracle):
+    """BASELINE config 4's frame size on one GPU: 7680x4320 over the 1M-cell scene, sampled against the CPU walk."""
+    W, H = 7680, 4320
+    prims = S.mixed_field(n_side=1000, seed=0x100000)
+    lights = S.mixed_field_lights()
+    cam = capi.make_camera(**S.mixed_field_camera(res=(W, H)))
+    sc = capi.Scene.create(prims, lights)
+    ctx.upload(sc)
+    ctx.reset_counters()
+    rgb, ids = ctx.render(cam, max_scatters=0, want_ids=True)
+    c = ctx.counters()
+    hits = int((ids >= 0).sum())
+    assert c["primary_rays"] == W * H and c["primary_hits"] == hits and c["shadow_rays"] == 4 * hits
+    step = 48
+    want_ids, want_rgb, _, _ = oracle.bvh_render(oracle.scene(prims, lights), oracle_bvh(oracle, sc), ocamera(cam), step=step)
+    assert np.array_equal(ids[::step, ::step], want_ids)
+    diff = np.abs(rgb[::step, ::step].astype(np.int16) - want_rgb.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).any(-1).mean() < 1e-3
