@@ -478,3 +478,41 @@ def test_textured_scene(ctx, tmp_path):
     ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
     ctx.synchronize()
     assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), full)
+
+
+def test_frame_replays_from_a_hip_graph(ctx):
+    """After one warm-up frame (which sizes the context's working set) a frame is memsets and launches only, so it can
+    be captured on the caller's stream and replayed; the replayed frames equal the directly rendered ones."""
+    import torch
+    prims, lights, camd = S.random_scene(60, 21, lights=3)
+    cam = capi.make_camera(**dict(camd, res=(256, 144)))
+    ctx.upload(capi.Scene.create(prims, lights))
+    want0 = ctx.render(cam, max_scatters=0)
+    want2 = ctx.render(cam, max_scatters=2)
+    W, H = 256, 144
+    out0 = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    out2 = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            ctx.set_stream(side.cuda_stream)
+            ctx.render_rect_dev(cam, (0, 0, W, H), out0.data_ptr(), None, 0, 0.0)       # warm-up on this stream
+            ctx.render_rect_dev(cam, (0, 0, W, H), out2.data_ptr(), None, 2, 0.0)
+            side.synchronize()
+            out0.zero_(); out2.zero_()
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                ctx.render_rect_dev(cam, (0, 0, W, H), out0.data_ptr(), None, 0, 0.0)
+                ctx.render_rect_dev(cam, (0, 0, W, H), out2.data_ptr(), None, 2, 0.0)
+            assert not out0.any().item()                     # capture launched nothing
+            for _ in range(2):
+                graph.replay()
+                torch.cuda.synchronize()
+                assert np.array_equal(out0.cpu().numpy().reshape(H, W, 3), want0)
+                assert np.array_equal(out2.cpu().numpy().reshape(H, W, 3), want2)
+                out0.zero_(); out2.zero_()
+                torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
