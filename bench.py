@@ -100,11 +100,19 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_SHARE_GPU=1): every rank uses GPU 0 and the tiles travel
+    # over gloo through host memory.  It checks the flow, not the speed; the driver never sets it.
+    rehearsal = os.environ.get("RT_BENCH_SHARE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = (int(v) for v in args.res.lower().split("x"))
     half = args.n_side / 2.0
@@ -209,7 +217,8 @@ def main():
                             % (W, H, len(lights)),
                 "n_side": args.n_side, "n_prims": int(info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
                 "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
-                "partition": "image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world if world > 1 else "single GPU",
+                "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world
+                              + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
                 "shadow_rays": total["shadow_rays"], "scene_build_s": round(build_s, 3),
                 "arithmetic": "FP32 padded-box traversal, FP64 leaf tests and shading",

@@ -70,5 +70,14 @@ class TileGather:
             if self.rank == 0:
                 self.gathered.copy_(self.local)
             return self.gathered
+        if self.local.is_cuda and self.dist.get_backend() == "gloo":
+            # rehearsal transport (several ranks sharing one GPU): stage through host memory
+            host = self.local.cpu()
+            parts = [host.new_empty(host.shape) for _ in range(self.n_ranks)] if self.rank == 0 else None
+            self.dist.gather(host, parts, dst=0)
+            if self.rank == 0:
+                for view, part in zip(self._views, parts):
+                    view.copy_(part)
+            return self.gathered
         self.dist.gather(self.local, self._views, dst=0)
         return self.gathered

@@ -71,3 +71,45 @@ def test_pack_then_assemble_is_identity():
         frame = known_frame(w, h)
         gathered = np.concatenate([tiles.pack_rank_tiles(frame, tile, n, r) for r in range(n)])
         assert np.array_equal(tiles.assemble(gathered, w, h, tile, n), frame)
+
+
+def gpu_worker(rank, world, port, out_path):
+    """One process per rank, all on GPU 0: render this rank's tiles with the real kernels, gather, assemble."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import scenes as S
+        prims, lights, camd = S.random_scene(90, 6, lights=2)
+        W, H, tile = 232, 120, 32
+        cam = capi.make_camera(**dict(camd, res=(W, H)))
+        ctx = capi.Context(0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.upload(capi.Scene.create(prims, lights))
+        tiling = capi.Tiling(W, H, tile, world)
+        tg = tiles.TileGather(torch, dist, W, H, tile, world, rank, "cuda")
+        for ms in (0, 2):
+            ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), ms, 0.0)
+            torch.cuda.synchronize()
+            gathered = tg.gather()
+            if rank == 0:
+                frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
+                ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+                torch.cuda.synchronize()
+                ctx.use_own_stream()
+                want = ctx.render(cam, max_scatters=ms)
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), want), ms
+            dist.barrier()
+        ctx.close()
+        if rank == 0:
+            open(out_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_render_gather_assemble_on_the_gpu(tmp_path, world):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(gpu_worker, args=(world, free_port(), out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
