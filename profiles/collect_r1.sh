@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-1 measurement recipe, run on the GPU box from the repository root:
+# Measurement recipe, run on the GPU box from the repository root:
 #   bash profiles/collect_r1.sh
 # bench line, rocprofv3 kernel stats of the same command, and two PMC passes (read and write side) for HBM traffic.
 set -u

@@ -54,8 +54,8 @@ def test_medium_mixed_field_full_frame(ctx, oracle):
     assert np.array_equal(gid, brute["id"]) and np.array_equal(bits(gdist), bits(brute["dist"]))
 
 
-def test_config3_one_million_cells_4k(ctx, oracle):
-    """BASELINE config 3: 1M-cell mixed scene, 3840x2160, primary + shadow rays to 4 lights."""
+def test_one_million_cells_4k(ctx, oracle):
+    """The benchmark workload: 1M-cell mixed scene, 3840x2160, primary + shadow rays to 4 lights."""
     import torch
     W, H = 3840, 2160
     prims = S.mixed_field(n_side=1000, seed=0x100000)
@@ -85,7 +85,7 @@ def test_config3_one_million_cells_4k(ctx, oracle):
     brute = oracle.trace_rays(oracle.scene(prims, lights), rays)
     assert np.array_equal(ids[py, px], brute["id"])
     assert np.array_equal(bits(tdist[py, px]), bits(brute["dist"]))
-    # config 4's partition on this frame: 8 virtual ranks, 64-pixel tiles
+    # the 8-GPU partition on this frame: 8 virtual ranks, 64-pixel tiles
     tiling = capi.Tiling(W, H, 64, 8)
     per = capi.tiles_per_rank(tiling) * 64 * 64 * 3
     gathered = torch.empty(8 * per, dtype=torch.uint8, device="cuda")
@@ -97,8 +97,8 @@ def test_config3_one_million_cells_4k(ctx, oracle):
     assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), rgb)
 
 
-def test_config2_cube_field_as_triangles(ctx, oracle):
-    """BASELINE config 2: 8334 cubes -> 100 008 triangles, 1920x1080, primary rays only.  The reference has no
+def test_cube_field_as_triangles(ctx, oracle):
+    """The triangle workload: 8334 cubes -> 100 008 triangles, 1920x1080, primary rays only.  The reference has no
     triangle: triangle id // 12 must equal the reference Cube's id and the distance agree to 1e-6 relative."""
     cubes = S.cube_field()
     cam = capi.make_camera(**S.CUBE_FIELD_CAMERA)
@@ -162,8 +162,8 @@ def test_mirror_bounces_on_a_dense_field(ctx, oracle):
     assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), rgb)
 
 
-def test_config4_8k_frame(ctx, oracle):
-    """BASELINE config 4's frame size on one GPU: 7680x4320 over the 1M-cell scene, sampled against the CPU walk."""
+def test_8k_frame(ctx, oracle):
+    """The 8K workload's frame size on one GPU: 7680x4320 over the 1M-cell scene, sampled against the CPU walk."""
     W, H = 7680, 4320
     prims = S.mixed_field(n_side=1000, seed=0x100000)
     lights = S.mixed_field_lights()
