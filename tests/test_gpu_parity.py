@@ -516,3 +516,30 @@ def test_frame_replays_from_a_hip_graph(ctx):
                 torch.cuda.synchronize()
     finally:
         ctx.use_own_stream()
+
+
+def test_more_lights_than_one_shadow_launch_holds(ctx, oracle):
+    """Eleven lights: two shadow launches (8 + 3) with the running light sum parked in between, plain and with bounces,
+    in rectangle and in tile mode.  The oracle sums the lights in the same (file) order."""
+    import torch
+    prims, lights, camd = S.random_scene(50, 91, lights=11)
+    lights["intensity"] *= 0.25
+    cam = capi.make_camera(**dict(camd, res=(192, 108)))
+    ctx.upload(capi.Scene.create(prims, lights))
+    osc = oracle.scene(prims, lights)
+    ctx.reset_counters()
+    for ms in (0, 2):
+        want, _, _ = oracle.render(osc, ocamera(cam), max_scatters=ms, threads=8)
+        got = ctx.render(cam, max_scatters=ms)
+        assert_rgb_close(got, want, max_frac=2e-3)
+        tiling = capi.Tiling(192, 108, 32, 2)
+        per = capi.tiles_per_rank(tiling) * 32 * 32 * 3
+        gathered = torch.empty(2 * per, dtype=torch.uint8, device="cuda")
+        for r in range(2):
+            ctx.render_tiles_dev(cam, tiling, r, gathered.data_ptr() + r * per, ms, 0.0)
+        frame = torch.empty(108 * 192 * 3, dtype=torch.uint8, device="cuda")
+        ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(frame.cpu().numpy().reshape(108, 192, 3), got)
+    c = ctx.counters()
+    assert c["shadow_rays"] % 11 == 0
