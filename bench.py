@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--max-scatters", type=int, default=0)
+    ap.add_argument("--device-build", action="store_true", help="build the hierarchy on the GPU (Morton order, balanced tree)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def main():
     lights = S.mixed_field_lights(half_extent=half, height=120.0 * half / 500.0, intensity=4000.0 * (half / 500.0) ** 2)
     camd = S.mixed_field_camera(half_extent=half, res=(W, H))
     t0 = time.perf_counter()
-    scene = capi.Scene.create(prims, lights, max_leaf=args.max_leaf)
+    scene = capi.Scene.create(prims, lights, max_leaf=args.max_leaf, on_device=args.device_build)
     build_s = time.perf_counter() - t0
     info = scene.info()
     cam = capi.make_camera(**camd)
@@ -221,6 +222,8 @@ def main():
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
                 "shadow_rays": total["shadow_rays"], "scene_build_s": round(build_s, 3),
+                "hierarchy": "balanced tree over Morton order, built on the GPU in %.2f ms" % ctx.build_time_ms() if args.device_build
+                             else "binned SAH, built on the host",
                 "arithmetic": "FP32 padded-box traversal, FP64 leaf tests and shading",
             },
             "roofline": {
@@ -237,7 +240,7 @@ def main():
                 "prims_per_shadow_ray": c["prims_shadow"] / max(c["shadow_rays"], 1),
             },
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and not args.device_build:
             out["cpu_baseline"] = cpu_baseline(scene, prims, lights, camd, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if dist is not None:

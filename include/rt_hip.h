@@ -71,8 +71,14 @@ typedef struct rt_node32 { float lo[3]; uint32_t first; float hi[3]; uint32_t co
 typedef struct rt_build_opts {
     uint32_t max_leaf;        /* primitives per leaf, 1..8 (0 = default 1) */
     uint32_t sah_bins;        /* 4..32 (0 = default 32) */
-    uint32_t reserved[6];
+    uint32_t flags;           /* RT_BUILD_* */
+    uint32_t reserved[5];
 } rt_build_opts;
+/* Leave the hierarchy to the GPU: no tree is built on the host, rt_scene_upload sorts the primitives along a Morton
+ * curve and builds a balanced tree on the device (milliseconds for a million primitives, for scenes that change every
+ * frame; rays visit more nodes than in the host's SAH tree, results are the same).  rt_scene_get_bvh has nothing to
+ * return for such a scene; rt_ctx_download_bvh fetches what the device built. */
+#define RT_BUILD_ON_DEVICE 1u
 
 typedef struct rt_scene_info {
     uint64_t n_prims;         /* primitives in id order */
@@ -161,6 +167,13 @@ int rt_ctx_use_own_stream(rt_ctx* ctx);
 int rt_ctx_synchronize(rt_ctx* ctx);
 /* Copy the scene to the context's GPU (synchronous; replaces a previously uploaded scene). */
 int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene);
+
+/* Milliseconds the last rt_scene_upload spent building the hierarchy on the device (0 for a host-built scene). */
+int rt_ctx_build_time(rt_ctx* ctx, double* ms_out);
+/* The uploaded hierarchy as the kernels walk it: up to node_capacity nodes and slot_capacity slot -> primitive id
+ * entries (bounded primitives in leaf order, then the unbounded ones); the counts are returned either way. */
+int rt_ctx_download_bvh(rt_ctx* ctx, rt_node32* nodes_out, uint32_t node_capacity, uint32_t* n_nodes_out,
+                        uint32_t* slot_prim_out, uint64_t slot_capacity, uint64_t* n_slots_out);
 
 /* RayTracer::get_one_ray_per_pixel + one_pass_intersection over a pixel rectangle (raytracer.cpp:123-157):
  * primary rays generated in registers, closest hit.  Outputs row-major in the rectangle; either may be NULL. */

@@ -40,7 +40,10 @@ class Tiling(C.Structure):
 
 
 class BuildOpts(C.Structure):
-    _fields_ = [("max_leaf", C.c_uint32), ("sah_bins", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("max_leaf", C.c_uint32), ("sah_bins", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+
+
+BUILD_ON_DEVICE = 1
 
 
 class SceneInfo(C.Structure):
@@ -93,6 +96,8 @@ SYMBOLS = [
     ("rt_ctx_use_own_stream", C.c_int, [_VP]),
     ("rt_ctx_synchronize", C.c_int, [_VP]),
     ("rt_scene_upload", C.c_int, [_VP, _VP]),
+    ("rt_ctx_build_time", C.c_int, [_VP, C.POINTER(_D)]),
+    ("rt_ctx_download_bvh", C.c_int, [_VP, _VP, _U32, C.POINTER(_U32), _VP, _U64, C.POINTER(_U64)]),
     ("rt_trace_primary", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP, _VP]),
     ("rt_trace_rays", C.c_int, [_VP, _VP, _U64, _VP, _VP]),
     ("rt_shade_rays", C.c_int, [_VP, _VP, _U64, _VP]),
@@ -212,17 +217,18 @@ class Scene:
         self.h = handle
 
     @classmethod
-    def create(cls, prims, lights=None, max_leaf=0, sah_bins=0):
+    def create(cls, prims, lights=None, max_leaf=0, sah_bins=0, on_device=False):
+        """on_device: build no hierarchy on the host; Context.upload sorts and builds on the GPU."""
         prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, LIGHT_DT), dtype=LIGHT_DT)
-        opts = BuildOpts(max_leaf, sah_bins)
+        opts = BuildOpts(max_leaf, sah_bins, BUILD_ON_DEVICE if on_device else 0)
         h = C.c_void_p()
         _check(lib().rt_scene_create(_ptr(prims), len(prims), _ptr(lights), len(lights), C.byref(opts), C.byref(h)))
         return cls(h)
 
     @classmethod
-    def load_json(cls, path, max_leaf=0, sah_bins=0):
-        opts = BuildOpts(max_leaf, sah_bins)
+    def load_json(cls, path, max_leaf=0, sah_bins=0, on_device=False):
+        opts = BuildOpts(max_leaf, sah_bins, BUILD_ON_DEVICE if on_device else 0)
         h = C.c_void_p()
         _check(lib().rt_scene_load_json(str(path).encode(), C.byref(opts), C.byref(h)))
         return cls(h)
@@ -339,6 +345,20 @@ class Context:
 
     def upload(self, scene):
         _check(lib().rt_scene_upload(self.h, scene.h))
+
+    def build_time_ms(self):
+        ms = C.c_double()
+        _check(lib().rt_ctx_build_time(self.h, C.byref(ms)))
+        return ms.value
+
+    def download_bvh(self):
+        """(nodes, slot_prim) of the uploaded hierarchy as the kernels walk it (host- or device-built)."""
+        nn, ns = C.c_uint32(), C.c_uint64()
+        _check(lib().rt_ctx_download_bvh(self.h, None, 0, C.byref(nn), None, 0, C.byref(ns)))
+        nodes = np.zeros(nn.value, dtype=NODE_DT)
+        slots = np.zeros(ns.value, dtype=np.uint32)
+        _check(lib().rt_ctx_download_bvh(self.h, _ptr(nodes), len(nodes), C.byref(nn), _ptr(slots), len(slots), C.byref(ns)))
+        return nodes, slots
 
     def set_counting(self, on):
         _check(lib().rt_ctx_set_counting(self.h, 1 if on else 0))

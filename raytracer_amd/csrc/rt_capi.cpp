@@ -49,6 +49,9 @@ struct rt_ctx {
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
     uint8_t* d_texels = nullptr; rt_tex_rec* d_tex_table = nullptr;
+    uint32_t* d_slot_prim = nullptr;       // slot -> primitive id, as uploaded or as the device build ordered it
+    uint32_t n_nodes_dev = 0; uint64_t n_slots_dev = 0;
+    double build_ms = 0.0;
     uint8_t* d_gamma = nullptr;            // 256 bytes of the display transfer table, then 256 bytes of identity
     unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
     uint32_t queue_used = kQueueSlots;     // slots consumed since the last zeroing
@@ -81,6 +84,8 @@ struct rt_ctx {
         if (d_lights) (void)hipFree(d_lights);
         if (d_texels) (void)hipFree(d_texels);
         if (d_tex_table) (void)hipFree(d_tex_table);
+        if (d_slot_prim) (void)hipFree(d_slot_prim);
+        d_slot_prim = nullptr;
         d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr; d_texels = nullptr; d_tex_table = nullptr;
         have_scene = false;
     }
@@ -266,6 +271,7 @@ int rt_scene_get_lights(const rt_scene* scene, const rt_light** lights, uint32_t
 
 int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n_nodes, const uint32_t** slot_prim, uint64_t* n_slots) {
     if (!scene || !nodes || !n_nodes || !slot_prim || !n_slots) return fail(RT_ERR_INVALID, "null argument");
+    if (scene->device_build) return fail(RT_ERR_NOT_FOUND, "this scene's hierarchy is built on the device: see rt_ctx_download_bvh");
     *nodes = scene->nodes.data(); *n_nodes = static_cast<uint32_t>(scene->nodes.size());
     *slot_prim = scene->slot_prim.data(); *n_slots = scene->n_slots;
     return RT_OK;
@@ -429,13 +435,94 @@ int rt_counters_read(rt_ctx* ctx, rt_counters* out) {
     return RT_OK;
 }
 
+namespace {
+
+// RT_BUILD_ON_DEVICE: records and FP32 boxes go over in id order; the device sorts them and builds the tree.
+int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
+    const uint32_t n = static_cast<uint32_t>(scene->n_slots);
+    const size_t total = scene->recs.size();                 // bounded, then unbounded
+    rt_prim_rec* d_in = nullptr; float* d_boxes = nullptr; uint32_t* d_order = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int rc = RT_OK;
+    auto check = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+    check(hipMalloc(reinterpret_cast<void**>(&d_in), total * sizeof(rt_prim_rec)), "hipMalloc");
+    if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&d_boxes), scene->boxes_f32.size() * sizeof(float)), "hipMalloc");
+    if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t)), "hipMalloc");
+    if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_nodes), 2ull * n * sizeof(rt_node32)), "hipMalloc");
+    if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_recs), total * sizeof(rt_prim_rec)), "hipMalloc");
+    if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_slot_prim), total * sizeof(uint32_t)), "hipMalloc");
+    if (rc == RT_OK) check(hipMemcpy(d_in, scene->recs.data(), total * sizeof(rt_prim_rec), hipMemcpyHostToDevice), "hipMemcpy");
+    if (rc == RT_OK) check(hipMemcpy(d_boxes, scene->boxes_f32.data(), scene->boxes_f32.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
+    if (rc == RT_OK) check(hipMemcpy(ctx->d_slot_prim, scene->slot_prim.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy");
+    if (rc == RT_OK) {
+        float bounds[6];
+        for (int k = 0; k < 3; ++k) {
+            bounds[k] = std::nextafterf(static_cast<float>(scene->info.bounds[k]), -INFINITY);
+            bounds[3 + k] = std::nextafterf(static_cast<float>(scene->info.bounds[3 + k]), INFINITY);
+        }
+        check(hipEventCreate(&t0), "hipEventCreate"); check(hipEventCreate(&t1), "hipEventCreate");
+        if (rc == RT_OK) {
+            (void)hipEventRecord(t0, ctx->stream);
+            check(rt_device_build(ctx->stream, n, d_boxes, bounds, d_in, ctx->d_nodes, ctx->d_recs, d_order), "device build");
+            // the unbounded primitives follow the sorted ones unchanged; slot -> id of the sorted part comes from the records
+            if (rc == RT_OK && total > n)
+                check(hipMemcpyAsync(ctx->d_recs + n, d_in + n, (total - n) * sizeof(rt_prim_rec), hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
+            if (rc == RT_OK) check(rt_launch_slot_ids(ctx->stream, ctx->d_recs, n, ctx->d_slot_prim), "slot ids");
+            (void)hipEventRecord(t1, ctx->stream);
+            check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+            float ms = 0.0f;
+            if (rc == RT_OK && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) ctx->build_ms = ms;
+        }
+    }
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    if (d_order) (void)hipFree(d_order);
+    if (d_boxes) (void)hipFree(d_boxes);
+    if (d_in) (void)hipFree(d_in);
+    ctx->n_nodes_dev = 2u * n;
+    return rc;
+}
+
+} // namespace
+
+int rt_ctx_build_time(rt_ctx* ctx, double* ms_out) {
+    if (!ctx || !ms_out) return fail(RT_ERR_INVALID, "null argument");
+    *ms_out = ctx->build_ms;
+    return RT_OK;
+}
+
+int rt_ctx_download_bvh(rt_ctx* ctx, rt_node32* nodes_out, uint32_t node_capacity, uint32_t* n_nodes_out,
+                        uint32_t* slot_prim_out, uint64_t slot_capacity, uint64_t* n_slots_out) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (n_nodes_out) *n_nodes_out = ctx->n_nodes_dev;
+    if (n_slots_out) *n_slots_out = ctx->n_slots_dev;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (nodes_out && ctx->n_nodes_dev) {
+        if (node_capacity < ctx->n_nodes_dev) return fail(RT_ERR_LIMIT, "node buffer too small");
+        RT_HIP(hipMemcpy(nodes_out, ctx->d_nodes, ctx->n_nodes_dev * sizeof(rt_node32), hipMemcpyDeviceToHost));
+    }
+    if (slot_prim_out && ctx->n_slots_dev) {
+        if (slot_capacity < ctx->n_slots_dev) return fail(RT_ERR_LIMIT, "slot buffer too small");
+        RT_HIP(hipMemcpy(slot_prim_out, ctx->d_slot_prim, ctx->n_slots_dev * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
 int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (!scene) return fail(RT_ERR_INVALID, "null scene");
     if (int rc = use(ctx)) return rc;
     RT_HIP(hipStreamSynchronize(ctx->stream));
     ctx->free_scene();
-    int rc = upload(scene->nodes, &ctx->d_nodes);
-    if (rc == RT_OK) rc = upload(scene->recs, &ctx->d_recs);
+    ctx->build_ms = 0.0;
+    ctx->n_nodes_dev = static_cast<uint32_t>(scene->nodes.size());
+    int rc = RT_OK;
+    if (scene->device_build && scene->n_slots > 0) {
+        rc = build_on_device(ctx, scene);
+    } else {
+        rc = upload(scene->nodes, &ctx->d_nodes);
+        if (rc == RT_OK) rc = upload(scene->recs, &ctx->d_recs);
+        if (rc == RT_OK) rc = upload(scene->slot_prim, &ctx->d_slot_prim);
+    }
     if (rc == RT_OK) rc = upload(scene->mats, &ctx->d_mats);
     if (rc == RT_OK) rc = upload(scene->lights, &ctx->d_lights);
     if (rc == RT_OK) rc = upload(scene->texels, &ctx->d_texels);
@@ -443,7 +530,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (rc != RT_OK) { ctx->free_scene(); return rc; }
     DevScene& d = ctx->sc;
     d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
-    d.n_nodes = static_cast<uint32_t>(scene->nodes.size());
+    d.n_nodes = ctx->n_nodes_dev;
+    ctx->n_slots_dev = scene->n_slots + scene->n_loose;
     d.n_slots = static_cast<uint32_t>(scene->n_slots);
     d.n_loose = static_cast<uint32_t>(scene->n_loose);
     d.n_lights = static_cast<uint32_t>(scene->lights.size());

@@ -24,6 +24,10 @@ struct rt_scene {
     rt_scene_info info{};
     // albedo textures (Mesh::setAlbedoTexture, mesh.h:47): pool of texels, one table entry per texture, and the
     // texture of each primitive (-1 = none)
+    // RT_BUILD_ON_DEVICE: no nodes here; recs / slot_prim are in id order and boxes_f32 (6 floats per bounded primitive,
+    // rounded outward) is what the device builds from
+    bool device_build = false;
+    std::vector<float>      boxes_f32;
     std::vector<uint8_t>    texels;
     std::vector<rt_tex_rec> tex_table;
     std::vector<int32_t>    prim_tex;

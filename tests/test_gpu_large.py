@@ -180,3 +180,21 @@ def test_8k_frame(ctx, oracle):
     assert np.array_equal(ids[::step, ::step], want_ids)
     diff = np.abs(rgb[::step, ::step].astype(np.int16) - want_rgb.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).any(-1).mean() < 1e-3
+
+
+def test_device_built_hierarchy_at_a_million_primitives(ctx):
+    """The 1M-cell scene with the hierarchy built on the GPU: same frame as with the host's SAH tree, byte for byte
+    (every primitive test is exact, so the tree cannot change a pixel); build time and depth as promised."""
+    W, H = 1920, 1080
+    prims = S.mixed_field(n_side=1000, seed=0x100000)
+    lights = S.mixed_field_lights()
+    cam = capi.make_camera(**S.mixed_field_camera(res=(W, H)))
+    host = capi.Scene.create(prims, lights)
+    ctx.upload(host)
+    want_rgb, want_ids = ctx.render(cam, max_scatters=0, want_ids=True)
+    dev = capi.Scene.create(prims, lights, on_device=True)
+    assert dev.info().depth == 21 and dev.info().n_nodes == 2 * dev.info().n_slots
+    ctx.upload(dev)
+    assert 0.0 < ctx.build_time_ms() < 100.0
+    rgb, ids = ctx.render(cam, max_scatters=0, want_ids=True)
+    assert np.array_equal(ids, want_ids) and np.array_equal(rgb, want_rgb)

@@ -543,3 +543,87 @@ def test_more_lights_than_one_shadow_launch_holds(ctx, oracle):
         assert np.array_equal(frame.cpu().numpy().reshape(108, 192, 3), got)
     c = ctx.counters()
     assert c["shadow_rays"] % 11 == 0
+
+
+def check_tree(nodes, slots, n_slots):
+    """Structural invariants of a flattened hierarchy: every slot in exactly one leaf, sibling pairs at even indices,
+    parents contain children, node 1 unused.  Returns the depth."""
+    seen = np.zeros(n_slots, dtype=np.int32)
+    depth, stack, visited = 0, [(0, 0)], 0
+    while stack:
+        k, d = stack.pop()
+        visited += 1
+        depth = max(depth, d)
+        first, count = int(nodes["first"][k]), int(nodes["count"][k])
+        if count:
+            seen[first:first + count] += 1
+        else:
+            assert first % 2 == 0 and first >= 2 and first + 1 < len(nodes)
+            for c in (first, first + 1):
+                assert (nodes["lo"][c] >= nodes["lo"][k]).all() and (nodes["hi"][c] <= nodes["hi"][k]).all()
+                stack.append((c, d + 1))
+    assert (seen == 1).all() and visited + 1 == len(nodes)
+    return depth
+
+
+@pytest.mark.parametrize("name,cam_id", SHIPPED)
+def test_hierarchy_built_on_the_device(ctx, oracle, name, cam_id):
+    """RT_BUILD_ON_DEVICE: Morton sort and balanced tree on the GPU.  A different tree, the same answers: ids and FP64
+    distances against the reference's, frames against its renders; the tree itself is downloaded and checked, and the
+    counting kernels agree with the CPU walk of that downloaded tree."""
+    g = np.load(os.path.join(GOLDEN, "shipped_%s.npz" % name))
+    sc = capi.Scene.load_json(os.path.join(SCENES, name + ".json"), on_device=True)
+    info = sc.info()
+    cam, _ = sc.camera(cam_id)
+    ctx.upload(sc)
+    assert ctx.build_time_ms() > 0.0
+    nodes, slots = ctx.download_bvh()
+    assert len(nodes) == info.n_nodes == 2 * info.n_slots and len(slots) == info.n_slots + info.n_loose
+    assert sorted(slots.tolist()) == sorted(set(slots.tolist()))
+    assert check_tree(nodes, slots, info.n_slots) == info.depth <= 31
+    ids, dist = ctx.trace_primary(cam)
+    assert np.array_equal(ids, g["ids"].astype(np.int32))
+    assert np.array_equal(bits(dist[::4]), bits(g["dist_rows"]))
+    for ms in (0, 2):
+        assert_rgb_close(ctx.render(cam, max_scatters=ms), g["render%d" % ms])
+    if "sec_rays" in g:
+        sid, sdist = ctx.trace_rays(g["sec_rays"])
+        assert np.array_equal(sid, g["sec_ids"].astype(np.int32)) and np.array_equal(bits(sdist), bits(g["sec_dist"]))
+    # node / primitive fetch counts of the device-built tree: GPU counting kernels == CPU walk of the downloaded tree
+    prims, lights = sc.prims(), sc.lights()
+    radius = float(np.nextafter(np.float32(info.radius), np.float32(np.inf)))
+    b = oracle.bvh(nodes, slots, info.n_slots, info.n_loose, radius)
+    _, _, counts, hits = oracle.bvh_render(oracle.scene(prims, lights), b, ocamera(cam))
+    ctx.set_counting(True); ctx.reset_counters()
+    ctx.render(cam, max_scatters=0)
+    c = ctx.counters()
+    ctx.set_counting(False)
+    if len(lights):
+        assert [c["nodes_primary"], c["prims_primary"], c["nodes_shadow"], c["prims_shadow"]] == counts.tolist()
+        assert c["primary_hits"] == hits
+
+
+def test_device_build_edge_sizes(ctx, oracle):
+    """0, 1, 2, 3, 5 and 64 primitives, unbounded ones mixed in: the closed-form tree shape at its corners."""
+    cam = capi.make_camera([0.3, -7, 2.5], [0, 1, -0.3], res=(96, 64))
+    lights = np.zeros(1, S.LIGHT_DT); lights["pos"] = [2, -3, 6]; lights["intensity"] = 40.0
+    for n in (0, 1, 2, 3, 5, 64):
+        prims, _, _ = S.random_scene(max(n, 1), 300 + n, lights=1)
+        prims = prims[:n]
+        if n >= 3:
+            extra = S.new_prims(1); extra["kind"] = S.SPHERE; extra["q"][0, :6] = [0.5, 0.5, 1.0, 0.7, 0.0, 0.6]   # zero scale: unbounded
+            prims = S.sort_reference_order(np.concatenate([prims, extra]))
+        sc = capi.Scene.create(prims, lights, on_device=True)
+        ctx.upload(sc)
+        info = sc.info()
+        nodes, slots = ctx.download_bvh()
+        assert len(nodes) == 2 * info.n_slots
+        if info.n_slots:
+            assert check_tree(nodes, slots, info.n_slots) == info.depth
+        want_ids, want_dist = oracle.trace_primary(oracle.scene(prims, lights), ocamera(cam))
+        ids, dist = ctx.trace_primary(cam)
+        assert np.array_equal(ids, want_ids) and np.array_equal(bits(dist), bits(want_dist)), n
+        want_rgb, _, _ = oracle.render(oracle.scene(prims, lights), ocamera(cam), max_scatters=1)
+        assert_rgb_close(ctx.render(cam, max_scatters=1), want_rgb, max_frac=2e-3)
+    with pytest.raises(capi.RtError):
+        capi.Scene.create(prims, lights, on_device=True).bvh()           # nothing on the host to hand out
