@@ -89,6 +89,8 @@ typedef struct rt_scene_info {
     uint32_t n_by_kind[8];
     double   bounds[6];       /* min xyz, max xyz of the bounded primitives */
     double   radius;          /* max |coordinate| of bounds and lights: scales the FP32 box padding */
+    uint64_t n_instances;     /* instanced scenes: instances, and the primitives they stand for (the id range) */
+    uint64_t n_instanced_prims;
 } rt_scene_info;
 
 /* Frame partition for multi-GPU runs: square tiles dealt round-robin (tile t -> rank t % n_ranks);
@@ -118,6 +120,19 @@ typedef struct rt_ctx rt_ctx;       /* one GPU: stream, device copy of a scene, 
  * FP32 boxes rounded outward, depth <= 31. */
 int rt_scene_create(const rt_prim_desc* prims, uint64_t n_prims, const rt_light* lights, uint32_t n_lights,
                     const rt_build_opts* opts_or_null, rt_scene** out);
+/* Two-level scenes (extension; the reference has no instancing).  The primitive list is a pool of meshes - a mesh is a
+ * contiguous run [first_prim, first_prim + n_prims) - and what rays see is the instances: each places one mesh with a
+ * rigid transform x_world = rot * x_mesh + trans (rot row-major, orthonormal; not checked).  The hierarchy has two
+ * levels, one tree per distinct mesh and one over the instances, so a scene of 10^4 instances of a 10^4-primitive mesh
+ * costs the memory of 2 * 10^4 items.  A ray is carried into an instance's frame as o' = rot^T (o - trans),
+ * d' = rot^T d, tested there with the ordinary intersectors, and the hit is carried back as p = rot p' + trans,
+ * n = rot n', r = rot r'; the distance is the one found in the instance's frame.  Hit ids: instance k owns the ids
+ * [base_k, base_k + n_prims_k), base_k = sum of n_prims over the instances before it; equal distances resolve to the
+ * lowest id.  Materials are those of the mesh primitive.  Every mesh primitive must be bounded (RT_ERR_INVALID
+ * otherwise); textures and RT_BUILD_ON_DEVICE are not available for such scenes; at most 2^31 - 1 ids. */
+typedef struct rt_instance { double rot[9]; double trans[3]; uint32_t first_prim, n_prims; } rt_instance;
+int rt_scene_create_instanced(const rt_prim_desc* prims, uint64_t n_prims, const rt_instance* instances, uint64_t n_instances,
+                              const rt_light* lights, uint32_t n_lights, const rt_build_opts* opts_or_null, rt_scene** out);
 /* RayTracer::load_from_json (raytracer.h:25, raytracer.cpp:107-121) for the Blender-export format, in
  * linear time, same defaults; the file's cameras are kept and served by rt_scene_camera. */
 int rt_scene_load_json(const char* path, const rt_build_opts* opts_or_null, rt_scene** out);
@@ -189,7 +204,8 @@ int rt_shade_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, uint8_t* rgb
 int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double* records16_dev);
 /* RayTracer::shade (raytracer.h:34, raytracer.cpp:159-279) for caller-supplied hits: 10 doubles each ([0..2] point,
  * [3..5] normal, [6] primitive id, [7..8] surface u, v, [9] non-zero when u, v are set; id -2 = a hit that names no
- * primitive, shaded white with the default material as the reference does; any other id outside the scene = black)
+ * primitive, shaded white with the default material as the reference does; any other id outside the scene = black;
+ * in an instanced scene the id names the mesh primitive, i.e. an index into the primitive pool)
  * and the origin of the ray that produced each hit (3 doubles).  Linear 8-bit colour. */
 int rt_shade_hits(rt_ctx* ctx, const double* hits10_dev, const double* view3_dev, uint64_t n, uint8_t* rgb_dev);
 /* RayTracer::render_unaccelerated_ppm's pixel loop with samples_per_pixel = 1 (raytracer.cpp:401-438):

@@ -27,9 +27,10 @@ PRIM_DT = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("q", "<f8", (12,)),
                     ("albedo", "<f8", (3,))])
 LIGHT_DT = np.dtype([("pos", "<f8", (3,)), ("intensity", "<f8")])
 HIT_DT = np.dtype([("hit", "<i4"), ("id", "<i4"), ("dist", "<f8"), ("p", "<f8", (3,)), ("n", "<f8", (3,)),
-                   ("r", "<f8", (3,)), ("u", "<f8"), ("v", "<f8")])
+                   ("r", "<f8", (3,)), ("u", "<f8"), ("v", "<f8"), ("prim", "<i4"), ("inst", "<i4")])
+INSTANCE_DT = np.dtype([("rot", "<f8", (9,)), ("trans", "<f8", (3,)), ("first_prim", "<u4"), ("n_prims", "<u4")])
 NODE_DT = np.dtype([("lo", "<f4", (3,)), ("first", "<u4"), ("hi", "<f4", (3,)), ("count", "<u4")])
-assert PRIM_DT.itemsize == 160 and LIGHT_DT.itemsize == 32 and HIT_DT.itemsize == 104 and NODE_DT.itemsize == 32
+assert PRIM_DT.itemsize == 160 and LIGHT_DT.itemsize == 32 and HIT_DT.itemsize == 112 and INSTANCE_DT.itemsize == 104 and NODE_DT.itemsize == 32
 
 
 class Camera(C.Structure):
@@ -48,7 +49,8 @@ class _Texture(C.Structure):
 
 class _Scene(C.Structure):
     _fields_ = [("prims", C.c_void_p), ("n_prims", C.c_int64), ("lights", C.c_void_p), ("n_lights", C.c_int64),
-                ("textures", C.c_void_p), ("n_textures", C.c_int64), ("prim_tex", C.c_void_p)]
+                ("textures", C.c_void_p), ("n_textures", C.c_int64), ("prim_tex", C.c_void_p),
+                ("instanced", C.c_int64), ("inst", C.c_void_p), ("n_inst", C.c_int64), ("inst_bounds", C.c_void_p)]
 
 
 def new_prims(n):
@@ -101,7 +103,7 @@ class Oracle:
         """textures: list of (h, w, 3) uint8 arrays; prim_tex: texture index per primitive (-1 = none)."""
         prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, LIGHT_DT), dtype=LIGHT_DT)
-        s = _Scene(_ptr(prims), len(prims), _ptr(lights), len(lights), None, 0, None)
+        s = _Scene(_ptr(prims), len(prims), _ptr(lights), len(lights), None, 0, None, 0, None, 0, None)
         s._keep = (prims, lights)
         if textures:
             arrs = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
@@ -110,6 +112,40 @@ class Oracle:
             assert len(pt) == len(prims)
             s.textures, s.n_textures, s.prim_tex = C.cast(table, C.c_void_p), len(arrs), _ptr(pt)
             s._keep += (arrs, table, pt)
+        return s
+
+    def _hit_bounds(self, p):
+        """Box that holds every point the intersector can return for p (the reference's own AABB of a plane spans the
+        four corners although its intersector walks the parallelogram of corners 0, 1, 3)."""
+        if int(p["kind"]) == PLANE:
+            q = p["q"]
+            p0, p1, p3 = q[0:3], q[3:6], q[9:12]
+            c = np.stack([p0, p1, p3, p1 + p3 - p0])
+            return np.concatenate([c.min(0), c.max(0)])
+        return self.aabb(p)
+
+    def instanced_scene(self, prims, instances, lights=None, skip_far_instances=True):
+        """Two-level scene (rto_instance).  skip_far_instances hands the oracle each mesh's bounds so that it can pass
+        over instances a ray cannot touch; results do not depend on it."""
+        s = self.scene(prims, lights)
+        inst = np.ascontiguousarray(instances, dtype=INSTANCE_DT)
+        s.instanced, s.inst, s.n_inst = 1, _ptr(inst), len(inst)
+        s._keep += (inst,)
+        if skip_far_instances and len(inst):
+            prims = s._keep[0]
+            boxes = np.array([self._hit_bounds(p) for p in prims]) if len(prims) else np.zeros((0, 6))
+            bounds = np.empty((len(inst), 6))
+            cache = {}
+            for k, it in enumerate(inst):
+                key = (int(it["first_prim"]), int(it["n_prims"]))
+                if key not in cache:
+                    b = boxes[key[0]:key[0] + key[1]]
+                    b = b[np.isfinite(b).all(axis=1)] if len(b) else b
+                    cache[key] = np.concatenate([b[:, :3].min(0), b[:, 3:].max(0)]) if len(b) else np.array([1.0, 1, 1, -1, -1, -1])
+                bounds[k] = cache[key]
+            bounds = np.ascontiguousarray(bounds)
+            s.inst_bounds = _ptr(bounds)
+            s._keep += (bounds,)
         return s
 
     def camera(self, pos, direction, up=None, focal=35.0, sensor=(36.0, 24.0), res=(1920, 1080)):

@@ -47,7 +47,7 @@ static double inv_or_zero(double s) { return (s != 0.0) ? (1.0 / s) : 0.0; }
 
 static void hit_clear(rto_hit* h) {
     memset(h, 0, sizeof(*h));
-    h->id = -1;
+    h->id = -1; h->prim = -1; h->inst = -1;
     h->dist = RTO_INF;
 }
 
@@ -367,13 +367,69 @@ void rto_aabb(const rto_prim* prim, double mn[3], double mx[3]) {
 
 /* RayTracer::one_pass_intersection, s2899221/Code/raytracer.cpp:143-157: strict '<', so the
  * lowest index wins exact ties. */
+/* Conservative "can this ray touch the box": FP64 slabs against bounds padded far beyond any rounding error. */
+static int may_touch(const double o[3], const double d[3], const double b[6]) {
+    double m = 1.0;
+    for (int k = 0; k < 6; ++k) if (fabs(b[k]) > m) m = fabs(b[k]);
+    for (int k = 0; k < 3; ++k) if (fabs(o[k]) > m) m = fabs(o[k]);
+    const double pad = 1e-9 * m;
+    double tn = 0.0, tf = RTO_INF;
+    for (int k = 0; k < 3; ++k) {
+        const double lo = b[k] - pad, hi = b[3 + k] + pad;
+        if (fabs(d[k]) < 1e-300) { if (o[k] < lo || o[k] > hi) return 0; continue; }
+        double t1 = (lo - o[k]) / d[k], t2 = (hi - o[k]) / d[k];
+        if (t1 > t2) { const double t = t1; t1 = t2; t2 = t; }
+        if (t1 > tn) tn = t1;
+        if (t2 < tf) tf = t2;
+    }
+    return tn <= tf * (1.0 + 1e-9) + pad;
+}
+
+/* Closest hit over the instances of a two-level scene (see rto_instance). */
+static int inst_closest_hit(const rto_scene* sc, const double o[3], const double d[3], rto_hit* out) {
+    rto_hit best; hit_clear(&best);
+    int any = 0;
+    int64_t base = 0;
+    for (int64_t k = 0; k < sc->n_inst; ++k) {
+        const rto_instance* in = &sc->inst[k];
+        const double* R = in->rot;
+        const double e[3] = { o[0] - in->trans[0], o[1] - in->trans[1], o[2] - in->trans[2] };
+        double oo[3], dd[3];
+        for (int i = 0; i < 3; ++i) {
+            oo[i] = R[i]*e[0] + R[3 + i]*e[1] + R[6 + i]*e[2];
+            dd[i] = R[i]*d[0] + R[3 + i]*d[1] + R[6 + i]*d[2];
+        }
+        if (!sc->inst_bounds || may_touch(oo, dd, sc->inst_bounds + 6*k)) {
+            for (uint32_t j = 0; j < in->n_prims; ++j) {
+                rto_hit h;
+                if (rto_intersect(&sc->prims[in->first_prim + j], oo, dd, &h) && h.dist < best.dist) {
+                    best = h; best.id = (int32_t)(base + j); best.prim = (int32_t)(in->first_prim + j); best.inst = (int32_t)k;
+                    any = 1;
+                }
+            }
+        }
+        base += in->n_prims;
+    }
+    if (!any) { hit_clear(out); return 0; }
+    const rto_instance* in = &sc->inst[best.inst];
+    const double* R = in->rot;
+    *out = best;
+    for (int i = 0; i < 3; ++i) {
+        out->p[i] = R[3*i]*best.p[0] + R[3*i + 1]*best.p[1] + R[3*i + 2]*best.p[2] + in->trans[i];
+        out->n[i] = R[3*i]*best.n[0] + R[3*i + 1]*best.n[1] + R[3*i + 2]*best.n[2];
+        out->r[i] = R[3*i]*best.r[0] + R[3*i + 1]*best.r[1] + R[3*i + 2]*best.r[2];
+    }
+    return 1;
+}
+
 int rto_closest_hit(const rto_scene* sc, const double o[3], const double d[3], rto_hit* out) {
+    if (sc->instanced) return inst_closest_hit(sc, o, d, out);
     rto_hit best; hit_clear(&best);
     int any = 0;
     for (int64_t i = 0; i < sc->n_prims; ++i) {
         rto_hit h;
         if (rto_intersect(&sc->prims[i], o, d, &h)) {
-            if (h.dist < best.dist) { best = h; best.id = (int32_t)i; any = 1; }
+            if (h.dist < best.dist) { best = h; best.id = (int32_t)i; best.prim = (int32_t)i; any = 1; }
         }
     }
     if (any) *out = best; else hit_clear(out);
@@ -402,9 +458,9 @@ static void albedo_u8(const rto_prim* m, uint8_t c[3]) {
 }
 /* Mesh::evaluate_albedo, s2899221/Code/mesh.cpp:21-45: texture (wrap, nearest) when there is one, else solid. */
 static void albedo_at(const rto_scene* sc, const rto_hit* hit, uint8_t c[3]) {
-    const rto_prim* m = &sc->prims[hit->id];
-    if (sc->prim_tex && sc->textures && sc->prim_tex[hit->id] >= 0 && sc->prim_tex[hit->id] < sc->n_textures) {
-        const rto_texture* t = &sc->textures[sc->prim_tex[hit->id]];
+    const rto_prim* m = &sc->prims[hit->prim];
+    if (sc->prim_tex && sc->textures && sc->prim_tex[hit->prim] >= 0 && sc->prim_tex[hit->prim] < sc->n_textures) {
+        const rto_texture* t = &sc->textures[sc->prim_tex[hit->prim]];
         const int w = t->width, h = t->height;
         if (w > 0 && h > 0) {
             double u = hit->u, v = hit->v;
@@ -455,7 +511,7 @@ static void shade_with(const rto_scene* sc, const rto_hit* hit, const double ray
     const double* p = hit->p;
     double v[3]; normalize3(ray_o[0] - p[0], ray_o[1] - p[1], ray_o[2] - p[2], v);
 
-    const rto_prim* m = (hit->id >= 0) ? &sc->prims[hit->id] : 0;
+    const rto_prim* m = (hit->prim >= 0) ? &sc->prims[hit->prim] : 0;
     const double metallic_factor = m ? clampd(m->metallic, 0.0, 1.0) : 0.0;
 
     double lighting = 0.0;
@@ -514,7 +570,7 @@ static void trace_rec(const rto_scene* sc, const double o[3], const double d[3],
     if (depth >= max_scatters) return;
     if (!h.hit) return;
 
-    const rto_prim* m = &sc->prims[h.id];
+    const rto_prim* m = &sc->prims[h.prim];
     const double metallic = m->metallic;
     const double ior = m->ior;
     const double rd_len = sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
@@ -755,7 +811,7 @@ static int walk_slot(walk_state* w, uint32_t slot) {
     if (!rto_intersect(&w->c->sc->prims[pid], w->o, w->d, &h)) return 0;
     if (w->mode == 0) {
         if (h.dist < w->best.dist || (h.dist == w->best.dist && (int32_t)pid < w->best.id)) {
-            w->best = h; w->best.id = (int32_t)pid;
+            w->best = h; w->best.id = (int32_t)pid; w->best.prim = (int32_t)pid;
             w->limit = h.dist; w->limit_f = f32_up(w->limit);
         }
     } else {

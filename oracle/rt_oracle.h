@@ -59,7 +59,17 @@ typedef struct rto_hit {
     double  dist;        /* distance along the ray, +inf on miss */
     double  p[3], n[3], r[3];
     double  u, v;
+    int32_t prim;        /* primitive whose material applies: id, or in an instanced scene the mesh primitive */
+    int32_t inst;        /* instanced scenes: which instance was hit; -1 otherwise */
 } rto_hit;
+
+/* Two-level scenes (an extension of the product; the reference has no instancing): an instance places the run
+ * [first_prim, first_prim + n_prims) of the primitive list with x_world = rot * x_mesh + trans (rot row-major,
+ * orthonormal).  When a scene has instanced != 0 only the instances are visible.  A ray enters an instance as
+ * o' = rot^T (o - trans), d' = rot^T d and is tested there with the ordinary intersectors; the winning hit returns as
+ * p = rot p' + trans, n = rot n', r = rot r' with the distance found in the instance's frame.  Ids: instance k owns
+ * [base_k, base_k + n_prims_k), base_k = sum of n_prims of the instances before it; strict '<' over ascending ids. */
+typedef struct rto_instance { double rot[9]; double trans[3]; uint32_t first_prim, n_prims; } rto_instance;
 
 /* Albedo texture as Image keeps it (utils.h:129-151): 8-bit RGB, rows top to bottom. */
 typedef struct rto_texture { int32_t width, height; const uint8_t* rgb; } rto_texture;
@@ -69,6 +79,11 @@ typedef struct rto_scene {
     const rto_light* lights; int64_t n_lights;
     const rto_texture* textures; int64_t n_textures;   /* may be NULL / 0 */
     const int32_t* prim_tex;                           /* per primitive: index into textures or -1; may be NULL */
+    int64_t instanced;                                 /* non-zero: two-level scene, see rto_instance */
+    const rto_instance* inst; int64_t n_inst;
+    /* optional, 6 doubles per instance: bounds of its mesh in the mesh's frame (min xyz, max xyz).  Only used to skip
+     * instances a ray cannot touch (a padded FP64 slab test); results are the same with or without it. */
+    const double* inst_bounds;
 } rto_scene;
 
 /* 32-byte BVH node shared with the product's flattened layout: internal nodes have count == 0 and

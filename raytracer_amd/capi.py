@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .scenes import LIGHT_DT, PRIM_DT
+from .scenes import INSTANCE_DT, LIGHT_DT, PRIM_DT
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "librt_hip.so")
@@ -49,7 +49,8 @@ BUILD_ON_DEVICE = 1
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint64), ("n_slots", C.c_uint64), ("n_loose", C.c_uint64),
                 ("n_nodes", C.c_uint32), ("depth", C.c_uint32), ("n_lights", C.c_uint32), ("n_cameras", C.c_uint32),
-                ("n_by_kind", C.c_uint32 * 8), ("bounds", C.c_double * 6), ("radius", C.c_double)]
+                ("n_by_kind", C.c_uint32 * 8), ("bounds", C.c_double * 6), ("radius", C.c_double),
+                ("n_instances", C.c_uint64), ("n_instanced_prims", C.c_uint64)]
 
 
 class Counters(C.Structure):
@@ -75,6 +76,7 @@ _VP, _I32, _U32, _U64, _D = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_d
 _DP = C.POINTER(C.c_double)
 SYMBOLS = [
     ("rt_scene_create", C.c_int, [_VP, _U64, _VP, _U32, C.POINTER(BuildOpts), C.POINTER(_VP)]),
+    ("rt_scene_create_instanced", C.c_int, [_VP, _U64, _VP, _U64, _VP, _U32, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_load_json", C.c_int, [C.c_char_p, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_load_json_text", C.c_int, [C.c_char_p, _U64, C.POINTER(BuildOpts), C.POINTER(_VP)]),
     ("rt_scene_set_textures", C.c_int, [_VP, _VP, _U32, _VP]),
@@ -224,6 +226,18 @@ class Scene:
         opts = BuildOpts(max_leaf, sah_bins, BUILD_ON_DEVICE if on_device else 0)
         h = C.c_void_p()
         _check(lib().rt_scene_create(_ptr(prims), len(prims), _ptr(lights), len(lights), C.byref(opts), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def create_instanced(cls, prims, instances, lights=None, max_leaf=0, sah_bins=0):
+        """Two-level scene: prims is a pool of meshes, instances (INSTANCE_DT) place runs of it with rigid transforms."""
+        prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
+        instances = np.ascontiguousarray(instances, dtype=INSTANCE_DT)
+        lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, LIGHT_DT), dtype=LIGHT_DT)
+        opts = BuildOpts(max_leaf, sah_bins, 0)
+        h = C.c_void_p()
+        _check(lib().rt_scene_create_instanced(_ptr(prims), len(prims), _ptr(instances), len(instances), _ptr(lights), len(lights),
+                                               C.byref(opts), C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -49,6 +49,7 @@ struct rt_ctx {
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
     uint8_t* d_texels = nullptr; rt_tex_rec* d_tex_table = nullptr;
+    rt_inst_rec* d_inst = nullptr;         // two-level scenes
     uint32_t* d_slot_prim = nullptr;       // slot -> primitive id, as uploaded or as the device build ordered it
     uint32_t n_nodes_dev = 0; uint64_t n_slots_dev = 0;
     double build_ms = 0.0;
@@ -85,7 +86,8 @@ struct rt_ctx {
         if (d_texels) (void)hipFree(d_texels);
         if (d_tex_table) (void)hipFree(d_tex_table);
         if (d_slot_prim) (void)hipFree(d_slot_prim);
-        d_slot_prim = nullptr;
+        if (d_inst) (void)hipFree(d_inst);
+        d_slot_prim = nullptr; d_inst = nullptr;
         d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr; d_texels = nullptr; d_tex_table = nullptr;
         have_scene = false;
     }
@@ -172,6 +174,29 @@ int rt_scene_create(const rt_prim_desc* prims, uint64_t n_prims, const rt_light*
     return RT_OK;
 }
 
+int rt_scene_create_instanced(const rt_prim_desc* prims, uint64_t n_prims, const rt_instance* instances, uint64_t n_instances,
+                              const rt_light* lights, uint32_t n_lights, const rt_build_opts* opts, rt_scene** out) {
+    if (!out || (n_prims && !prims) || (n_lights && !lights) || (n_instances && !instances)) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n_prims >= (1ull << 28) || n_instances >= (1ull << 28)) return fail(RT_ERR_LIMIT, "scene too large");
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_LIMIT, "out of memory");
+    try {
+        s->prims.assign(prims, prims + n_prims);
+        s->lights.assign(lights, lights + n_lights);
+        s->instances.assign(instances, instances + n_instances);
+        s->instanced = true;
+        const int rc = rt_scene_finalize(s, opts);
+        if (rc != RT_OK) {
+            delete s;
+            return fail(rc, rc == RT_ERR_LIMIT ? "scene too large" :
+                        "instanced scene: a mesh run outside the primitive list, an unbounded mesh primitive, a transform that is not rigid, or an unsupported option");
+        }
+    } catch (const std::exception& e) { delete s; return fail(RT_ERR_LIMIT, e.what()); }
+    *out = s;
+    return RT_OK;
+}
+
 int rt_scene_load_json(const char* path, const rt_build_opts* opts, rt_scene** out) {
     if (!path || !out) return fail(RT_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -208,6 +233,7 @@ int rt_scene_load_json_text(const char* text, uint64_t len, const rt_build_opts*
 
 int rt_scene_set_textures(rt_scene* scene, const rt_texture* textures, uint32_t n_textures, const int32_t* prim_texture) {
     if (!scene || (n_textures && (!textures || !prim_texture))) return fail(RT_ERR_INVALID, "null argument");
+    if (scene->instanced) return fail(RT_ERR_INVALID, "textures are not available for instanced scenes");
     try {
         scene->texels.clear(); scene->tex_table.clear();
         scene->prim_tex.assign(scene->prims.size(), -1);
@@ -527,6 +553,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (rc == RT_OK) rc = upload(scene->lights, &ctx->d_lights);
     if (rc == RT_OK) rc = upload(scene->texels, &ctx->d_texels);
     if (rc == RT_OK) rc = upload(scene->tex_table, &ctx->d_tex_table);
+    if (rc == RT_OK) rc = upload(scene->inst_recs, &ctx->d_inst);
     if (rc != RT_OK) { ctx->free_scene(); return rc; }
     DevScene& d = ctx->sc;
     d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
@@ -538,6 +565,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.n_prims = static_cast<uint32_t>(scene->prims.size());
     d.texels = ctx->d_texels; d.tex_table = ctx->d_tex_table;
     d.n_textures = static_cast<uint32_t>(scene->tex_table.size());
+    d.inst = ctx->d_inst; d.n_inst = static_cast<uint32_t>(scene->inst_recs.size());
     // round the radius up: the padding must not shrink through the conversion
     d.radius = std::nextafterf(static_cast<float>(scene->info.radius), INFINITY);
     if (!std::isfinite(d.radius)) d.radius = 3.0e38f;

@@ -26,6 +26,8 @@ struct DevScene {
     const uint8_t*     gamma;      // 256-entry table
     const uint8_t*     texels;     // albedo textures, 8-bit RGB
     const rt_tex_rec*  tex_table;
+    const rt_inst_rec* inst;       // two-level scenes: instances in the leaf order of the top-level tree
+    uint32_t n_inst;
     uint32_t n_nodes, n_slots, n_loose, n_lights, n_prims, n_textures;
     float radius;                  // max |coordinate| of the scene: scales the box padding
 };

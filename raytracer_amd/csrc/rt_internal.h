@@ -30,6 +30,18 @@ struct rt_mat_rec {
 // One albedo texture inside the scene's texel pool (8-bit RGB, rows top to bottom).
 struct rt_tex_rec { uint64_t offset; int32_t width, height; };
 
+// One instance of a two-level scene, 128 bytes, in the leaf order of the tree over the instances.
+struct rt_inst_rec {
+    double   rot[9];               // mesh frame -> world, row-major
+    double   trans[3];
+    uint32_t root_ref;             // node reference the walk starts from inside the mesh's tree
+    int32_t  id_off;               // hit id = record id + id_off (first id of the instance - first primitive of its mesh)
+    float    radius;               // max |coordinate| of the mesh in its own frame: scales the box padding there
+    uint32_t index;                // position in the caller's instance list
+    uint32_t pad[4];
+};
+
+#define RT_STACK_DEPTH_INST 64     // two-level scenes: both trees and the marker between them
 #define RT_STACK_DEPTH 32          // traversal stack entries per lane; the builder keeps depth <= 31
 #define RT_MAX_SCATTERS 8
 #define RT_PAD_SHIFT 18            // FP32 box padding = 2^-18 * max(|ray origin|, scene radius)
@@ -37,6 +49,7 @@ struct rt_tex_rec { uint64_t offset; int32_t width, height; };
 #ifdef __cplusplus
 static_assert(sizeof(rt_prim_rec) == 160, "record layout");
 static_assert(sizeof(rt_mat_rec) == 32, "material layout");
+static_assert(sizeof(rt_inst_rec) == 128, "instance layout");
 static_assert(sizeof(rt_node32) == 32, "node layout");
 static_assert(sizeof(rt_prim_desc) == 160, "description layout");
 #endif

@@ -304,7 +304,7 @@ DEV bool ref_internal(uint32_t r) { return (r >> 28) == 0u; }
 
 // Per-lane stack: entries 0..RT_STACK_LDS-1 in LDS ([entry][lane]), deeper ones in a private array that lives
 // outside this struct (a dynamically indexed member would drag every field of the walker into scratch memory).
-struct DeepStack { uint2 e[RT_STACK_DEPTH - RT_STACK_LDS]; };
+template <bool INST> struct DeepStack { uint2 e[(INST ? RT_STACK_DEPTH_INST : RT_STACK_DEPTH) - RT_STACK_LDS]; };
 // The LDS part is one file-scope array, indexed directly, so that the compiler emits ds_read / ds_write (a pointer
 // kept in a struct degrades to flat addressing).  Every ray kernel runs one wave per workgroup.
 __shared__ uint2 g_lds_stack[RT_STACK_LDS * 64];
@@ -328,7 +328,33 @@ struct Stack {
     }
 };
 
-struct Best { double dist; uint32_t slot; int32_t id; };
+struct Best { double dist; uint32_t slot; int32_t id; uint32_t inst; };
+
+// Two-level scenes.  A ray enters an instance as o' = rot^T (o - trans), d' = rot^T d; what it finds there comes back
+// as p = rot p' + trans and n = rot n', r = rot r'.  The distance is the one found in the instance's frame.
+constexpr uint32_t REF_LEAVE = 0xFFFFFFFEu;        // stack marker: the walk is back in the top-level tree
+DEV void ray_into_instance(const rt_inst_rec* in, const RayD& w, RayD& o) {
+    double c[18];
+    load_rec<12>(reinterpret_cast<const rt_prim_rec*>(in), c);          // rot[0..8], trans[9..11]
+    const double ex = w.ox - c[9], ey = w.oy - c[10], ez = w.oz - c[11];
+    o.ox = c[0]*ex + c[3]*ey + c[6]*ez;
+    o.oy = c[1]*ex + c[4]*ey + c[7]*ez;
+    o.oz = c[2]*ex + c[5]*ey + c[8]*ez;
+    o.dx = c[0]*w.dx + c[3]*w.dy + c[6]*w.dz;
+    o.dy = c[1]*w.dx + c[4]*w.dy + c[7]*w.dz;
+    o.dz = c[2]*w.dx + c[5]*w.dy + c[8]*w.dz;
+    o.dlen = dsqrt(o.dx*o.dx + o.dy*o.dy + o.dz*o.dz);
+}
+DEV void hit_out_of_instance(const rt_inst_rec* in, HitD& h) {
+    double c[18];
+    load_rec<12>(reinterpret_cast<const rt_prim_rec*>(in), c);
+    const double px = c[0]*h.px + c[1]*h.py + c[2]*h.pz + c[9];
+    const double py = c[3]*h.px + c[4]*h.py + c[5]*h.pz + c[10];
+    const double pz = c[6]*h.px + c[7]*h.py + c[8]*h.pz + c[11];
+    const double nx = c[0]*h.nx + c[1]*h.ny + c[2]*h.nz, ny = c[3]*h.nx + c[4]*h.ny + c[5]*h.nz, nz = c[6]*h.nx + c[7]*h.ny + c[8]*h.nz;
+    const double rx = c[0]*h.rx + c[1]*h.ry + c[2]*h.rz, ry = c[3]*h.rx + c[4]*h.ry + c[5]*h.rz, rz = c[6]*h.rx + c[7]*h.ry + c[8]*h.rz;
+    h.px = px; h.py = py; h.pz = pz; h.nx = nx; h.ny = ny; h.nz = nz; h.rx = rx; h.ry = ry; h.rz = rz;
+}
 
 // One ray's walk through the BVH as a resumable state machine, so that a wave can interleave the walks of its
 // lanes ("while-while") and swap finished rays for fresh ones.
@@ -337,9 +363,11 @@ struct Best { double dist; uint32_t slot; int32_t id; };
 // beyond light_dist - 1e-4 are irrelevant; once one hit inside the interval is known only hits at
 // <= 1e-4 can still change the verdict, so the search limit collapses to 1e-4; any such hit ends it.
 // vn counts node records fetched (1 for the root, 2 per internal node visited), vp primitive records.
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool INST = false>
 struct Walker {
-    RayD r;
+    RayD r;                             // in the frame being walked: the world, or the current instance's
+    RayD rw;                            // INST: the ray in the world
+    uint32_t inst; int32_t id_off;      // INST: instance slot being walked (REF_NONE in the top level), its id offset
     BoxRay br;
     Stack st;
     uint32_t cur;
@@ -356,9 +384,10 @@ struct Walker {
         HitD h;
         if (!hit_record<false>(rec, tag.x, r, h)) return;
         if (MODE == 0) {
-            const int32_t id = static_cast<int32_t>(tag.y);
+            const int32_t id = static_cast<int32_t>(tag.y) + (INST ? id_off : 0);
             if (h.dist < best.dist || (h.dist == best.dist && id < best.id)) {
                 best.dist = h.dist; best.slot = slot; best.id = id;
+                if (INST) best.inst = inst;
                 limit = h.dist; limit_f = f32_up(limit);
             }
         } else {
@@ -370,10 +399,11 @@ struct Walker {
     // Root box test; afterwards cur is the first node reference or REF_NONE.
     DEV void start(const DevScene& sc, const RayD& ray, uint2* lds_stack, uint2* deep_stack, double ldist) {
         r = ray;
+        if (INST) { rw = ray; inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
         (void)lds_stack;
         st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
-        best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1;
+        best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
@@ -407,6 +437,26 @@ struct Walker {
 
     // cur is a leaf: test its primitives, then take the next postponed node.
     DEV void step_leaf(const DevScene& sc) {
+        if (INST) {
+            if (cur == REF_LEAVE) {                 // the instance is exhausted: back to the world
+                r = rw; inst = REF_NONE; id_off = 0;
+                box_ray_init(br, r, sc.radius);
+                cur = st.pop(limit_f);
+                return;
+            }
+            if (inst == REF_NONE) {                 // a leaf of the top-level tree: one instance
+                const uint32_t slot = cur & 0x0FFFFFFFu;
+                const rt_inst_rec* in = sc.inst + slot;
+                const uint4 tail = *reinterpret_cast<const uint4*>(&in->root_ref);
+                st.push(REF_LEAVE, 0.0f);
+                ray_into_instance(in, rw, r);
+                box_ray_init(br, r, __uint_as_float(tail.z));
+                inst = slot; id_off = static_cast<int32_t>(tail.y);
+                cur = tail.x;
+                if (COUNT) ++vn;
+                return;
+            }
+        }
         const uint32_t first = cur & 0x0FFFFFFFu, count = cur >> 28;
         for (uint32_t s = 0; s < count && !(MODE == 1 && closed); ++s) test_slot(sc, first + s);
         cur = (MODE == 1 && closed) ? REF_NONE : st.pop(limit_f);
@@ -421,11 +471,11 @@ struct Walker {
 };
 
 // A whole walk in one go (arbitrary-ray and bounce kernels).
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool INST = false>
 DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double light_dist,
                   Best& best, uint32_t& vn, uint32_t& vp) {
-    Walker<MODE, COUNT> w; w.vn = 0; w.vp = 0;
-    DeepStack deep;
+    Walker<MODE, COUNT, INST> w; w.vn = 0; w.vp = 0;
+    DeepStack<INST> deep;
     w.start(sc, r, lds_stack, deep.e, light_dist);
     while (!w.done()) {
         // inner nodes: the wave stays here until every lane holds a leaf or has run out of nodes
@@ -435,6 +485,23 @@ DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double li
     w.finish(sc);
     best = w.best; vn += w.vn; vp += w.vp;
     return MODE == 0 ? w.hit() : w.blocked();
+}
+
+// The full surface record of the hit a walk found, in the world; mat_id = the primitive whose material applies.
+template <bool UV, bool INST>
+DEV void best_record(const DevScene& sc, const Best& b, const RayD& world_ray, HitD& h, int32_t& mat_id) {
+    const rt_prim_rec* rec = sc.recs + b.slot;
+    const uint2 tag = *reinterpret_cast<const uint2*>(&rec->kind);
+    if (INST) {
+        const rt_inst_rec* in = sc.inst + b.inst;
+        RayD ro; ray_into_instance(in, world_ray, ro);
+        hit_record<true, UV>(rec, tag.x, ro, h);
+        hit_out_of_instance(in, h);
+        mat_id = static_cast<int32_t>(tag.y);
+    } else {
+        hit_record<true, UV>(rec, tag.x, world_ray, h);
+        mat_id = b.id;
+    }
 }
 
 // ---- shading -----------------------------------------------------------------------------------
@@ -494,7 +561,7 @@ DEV double light_value(const rt_light& L, const rt_mat_rec& m, double px, double
 }
 
 // One light's term of RayTracer::shade (raytracer.cpp:210-260) in one go; 0 when the light is blocked.
-template <bool COUNT>
+template <bool COUNT, bool INST = false>
 DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
                       double nx, double ny, double nz, double view_ox, double view_oy, double view_oz,
                       uint2* lds_stack, ShadeCounters& ctr) {
@@ -502,7 +569,7 @@ DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m
     const double light_dist = shadow_ray(L, px, py, pz, nx, ny, nz, sr);
     Best b;
     ++ctr.shadow_rays;
-    if (traverse<1, COUNT>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
+    if (traverse<1, COUNT, INST>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
     return light_value(L, m, px, py, pz, nx, ny, nz, sr.dx, sr.dy, sr.dz, view_ox, view_oy, view_oz);
 }
 
@@ -537,7 +604,7 @@ DEV uint32_t finish_shade(const rt_mat_rec& m, uint32_t albedo, double lighting)
 }
 
 // RayTracer::shade, raytracer.cpp:159-279, all lights in order inside one lane (megakernel path).
-template <bool COUNT>
+template <bool COUNT, bool INST = false>
 DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec& m, uint32_t albedo, double view_ox, double view_oy,
                             double view_oz, uint2* lds_stack, ShadeCounters& ctr) {
     if (sc.n_lights == 0) return 0;
@@ -545,17 +612,17 @@ DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec&
     double lighting = 0.0;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const rt_light L = sc.lights[li];
-        lighting += light_term<COUNT>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
+        lighting += light_term<COUNT, INST>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
     }
     return finish_shade(m, albedo, lighting);
 }
 
 // h must carry u, v when the scene has textures.
-template <bool COUNT>
+template <bool COUNT, bool INST = false>
 DEV uint32_t shade(const DevScene& sc, const HitD& h, int32_t id, double view_ox, double view_oy, double view_oz,
                    uint2* lds_stack, ShadeCounters& ctr) {
     const rt_mat_rec m = sc.mats[id];
-    return shade_material<COUNT>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, lds_stack, ctr);
+    return shade_material<COUNT, INST>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, lds_stack, ctr);
 }
 
 // Camera::pixelToRay, persp_camera.cpp:94-118 (effective sensor size precomputed on the host).
@@ -668,7 +735,7 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 //          RECORD & 4: the scene has textures - the albedo under the hit's (u, v) is stored with the record.
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
-template <int MODE, bool COUNT, int RECORD>
+template <int MODE, bool COUNT, int RECORD, bool INST = false>
 __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
@@ -676,8 +743,8 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     uint2* my_stack = nullptr;
     enum { IDLE = 0, TRAV = 1, DONE = 2 };
     uint32_t state = IDLE, out = 0, ridx = 0;
-    Walker<MODE, COUNT> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
-    DeepStack deep;
+    Walker<MODE, COUNT, INST> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
+    DeepStack<INST> deep;
     uint32_t n_cast = 0, n_hit = 0;
     uint32_t q_next = 0, q_end = 0;          // wave-uniform: the unread part of the current chunk
     bool q_empty = false;
@@ -700,12 +767,13 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     if (ids) ids[out] = w.best.id;
                     if (dist) dist[out] = w.best.dist;
                     if (RECORD) {
-                        fb.id[out] = w.best.id;
+                        // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
+                        int32_t mat_id = -1;
+                        HitD h;
+                        if (hit) best_record<(RECORD & 4) != 0, INST>(sc, w.best, INST ? w.rw : w.r, h, mat_id);
+                        fb.id[out] = mat_id;
                         if (hit) {
-                            HitD h;
-                            const rt_prim_rec* rec = sc.recs + w.best.slot;
-                            hit_record<true, (RECORD & 4) != 0>(rec, rec->kind, w.r, h);
-                            if (RECORD & 4) fb.albedo[out] = albedo_at(sc, sc.mats[w.best.id], h.u, h.v);
+                            if (RECORD & 4) fb.albedo[out] = albedo_at(sc, sc.mats[mat_id], h.u, h.v);
                             double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
                             fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
                             fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
@@ -721,8 +789,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         // the view vector points at the origin of the ray that found this surface (raytracer.cpp:185-186)
                         double vox = cam.pos[0], voy = cam.pos[1], voz = cam.pos[2];
                         if (fb.ray && fb.level > 0) { vox = fb.ray[out]; voy = fb.ray[fb.n + out]; voz = fb.ray[2*fb.n + out]; }
+                        const RayD& sr = INST ? w.rw : w.r;
                         c = light_value(L, m, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out],
-                                        w.r.dx, w.r.dy, w.r.dz, vox, voy, voz);
+                                        sr.dx, sr.dy, sr.dz, vox, voy, voz);
                     }
                     fb.contrib[static_cast<size_t>(lj) * fb.n + out] = c;
                 }
@@ -834,7 +903,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, FrameBufs fb, uint
 }
 
 // Arbitrary rays (origin, direction as 6 doubles): closest hit, optionally shaded (linear colour, no gamma).
-template <bool COUNT, bool SHADE>
+template <bool COUNT, bool SHADE, bool INST = false>
 __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __restrict__ rays, uint64_t n,
                                                    int32_t* __restrict__ ids, double* __restrict__ dist,
                                                    uint8_t* __restrict__ rgb, double* __restrict__ records, rt_counters* ctr) {
@@ -849,13 +918,14 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
         r.dx = rays[i*6 + 3]; r.dy = rays[i*6 + 4]; r.dz = rays[i*6 + 5];
         r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
         Best b;
-        hit = traverse<0, COUNT>(sc, r, my_stack, 0.0, b, vn, vp);
+        hit = traverse<0, COUNT, INST>(sc, r, my_stack, 0.0, b, vn, vp);
         if (ids) ids[i] = b.id;
         if (dist) dist[i] = b.dist;
         if (records) {      // the Hit of the reference (utils.h:68-112): 16 doubles per ray
             double* o = records + i * 16;
             HitD h; h.u = 0.0; h.v = 0.0;
-            if (hit) { const rt_prim_rec* rec = sc.recs + b.slot; hit_record<true, true>(rec, rec->kind, r, h); }
+            int32_t mat_id;
+            if (hit) best_record<true, INST>(sc, b, r, h, mat_id);
             o[0] = hit ? 1.0 : 0.0; o[1] = static_cast<double>(b.id); o[2] = b.dist;
             o[3] = hit ? h.px : 0.0; o[4] = hit ? h.py : 0.0; o[5] = hit ? h.pz : 0.0;
             o[6] = hit ? h.nx : 0.0; o[7] = hit ? h.ny : 0.0; o[8] = hit ? h.nz : 0.0;
@@ -866,9 +936,9 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
             uint32_t c = 0;
             if (hit) {
                 HitD h; h.u = 0.0; h.v = 0.0;
-                const rt_prim_rec* rec = sc.recs + b.slot;
-                hit_record<true, true>(rec, rec->kind, r, h);
-                c = shade<COUNT>(sc, h, b.id, r.ox, r.oy, r.oz, my_stack, sctr);
+                int32_t mat_id;
+                best_record<true, INST>(sc, b, r, h, mat_id);
+                c = shade<COUNT, INST>(sc, h, mat_id, r.ox, r.oy, r.oz, my_stack, sctr);
             }
             rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
         }
@@ -905,6 +975,7 @@ __global__ void __launch_bounds__(64) k_intersect_one(const rt_prim_rec* __restr
 
 // RayTracer::shade for caller-supplied hits: 10 doubles each (point, normal, primitive id, u, v, has-uv flag) and a
 // view origin (3 doubles) per hit; linear 8-bit colour out.
+template <bool INST>
 __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __restrict__ hits, const double* __restrict__ view,
                                                    uint64_t n, uint8_t* __restrict__ rgb, rt_counters* ctr) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
@@ -920,13 +991,13 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
             const rt_mat_rec m = sc.mats[static_cast<int32_t>(idf)];
             // a texture is only consulted when the Hit carries surface coordinates (mesh.cpp:23)
             const uint32_t alb = (hits[i*10 + 9] != 0.0) ? albedo_at(sc, m, h.u, h.v) : solid_albedo(m);
-            c = shade_material<false>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            c = shade_material<false, INST>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
         } else if (idf == -2.0) {
             // a hit that names no primitive: white, non-metallic, roughness 0.5 (raytracer.cpp:204-208, 250-254, 268-272)
             rt_mat_rec m;
             m.metallic = 0.0; m.roughness = 0.5; m.ior = 1.5; m.albedo[0] = 255; m.albedo[1] = 255; m.albedo[2] = 255;
             m.tex = -1;
-            c = shade_material<false>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            c = shade_material<false, INST>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
         }
         rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
     }
@@ -1060,11 +1131,20 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
     const uint32_t n_rays = n_tiles * 64u;
     const dim3 grid(n_waves), block(64);
     const int variant = !fb ? 0 : (1 | (fb->ray ? 2 : 0) | (fb->albedo ? 4 : 0));
-#define RT_LAUNCH_PRIMARY(R, FB)                                                                                                         \
+#define RT_LAUNCH_PRIMARY_I(R, FB, I)                                                                                                    \
     do {                                                                                                                                 \
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, R>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min);  \
-        else          hipLaunchKernelGGL((k_rays<0, false, R>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, R, I>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min);  \
+        else          hipLaunchKernelGGL((k_rays<0, false, R, I>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
     } while (0)
+#define RT_LAUNCH_PRIMARY(R, FB) RT_LAUNCH_PRIMARY_I(R, FB, false)
+    if (sc->inst) {                     // two-level scene (no textures there)
+        switch (variant) {
+            case 0: RT_LAUNCH_PRIMARY_I(0, none, true); break;
+            case 1: RT_LAUNCH_PRIMARY_I(1, *fb, true); break;
+            default: RT_LAUNCH_PRIMARY_I(3, *fb, true); break;
+        }
+        return hipGetLastError();
+    }
     switch (variant) {
         case 0: RT_LAUNCH_PRIMARY(0, none); break;
         case 1: RT_LAUNCH_PRIMARY(1, *fb); break;
@@ -1073,6 +1153,7 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
         default: RT_LAUNCH_PRIMARY(7, *fb); break;
     }
 #undef RT_LAUNCH_PRIMARY
+#undef RT_LAUNCH_PRIMARY_I
     return hipGetLastError();
 }
 
@@ -1080,6 +1161,11 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
                                        uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                                        const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t n_rays = n_tiles * n_batch * 64u;
+    if (sc->inst) {
+        if (counting) hipLaunchKernelGGL((k_rays<1, true, 0, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<1, false, 0, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+        return hipGetLastError();
+    }
     if (counting) hipLaunchKernelGGL((k_rays<1, true, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
     else          hipLaunchKernelGGL((k_rays<1, false, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
     return hipGetLastError();
@@ -1096,6 +1182,16 @@ extern "C" hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, c
                                            int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr) {
     const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
     if (nb == 0) return hipSuccess;
+    if (sc->inst) {
+        if (shade_it) {
+            if (counting) hipLaunchKernelGGL((k_trace_rays<true, true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
+            else          hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
+        } else {
+            if (counting) hipLaunchKernelGGL((k_trace_rays<true, false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
+            else          hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
+        }
+        return hipGetLastError();
+    }
     if (shade_it) {
         if (counting) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
         else          hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
@@ -1115,7 +1211,8 @@ extern "C" hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec*
 extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
                                            uint8_t* rgb, rt_counters* ctr) {
     const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
-    if (nb) hipLaunchKernelGGL(k_shade_hits, dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    if (nb && sc->inst) hipLaunchKernelGGL(k_shade_hits<true>, dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    else if (nb)        hipLaunchKernelGGL(k_shade_hits<false>, dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
     return hipGetLastError();
 }
 

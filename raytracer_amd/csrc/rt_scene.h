@@ -31,6 +31,11 @@ struct rt_scene {
     std::vector<uint8_t>    texels;
     std::vector<rt_tex_rec> tex_table;
     std::vector<int32_t>    prim_tex;
+    // two-level scenes: the caller's instances and their flattened records in the leaf order of the top-level tree
+    // (nodes then holds the top-level tree followed by one tree per distinct mesh)
+    bool instanced = false;
+    std::vector<rt_instance> instances;
+    std::vector<rt_inst_rec> inst_recs;
 };
 
 // rt_prep.cpp
