@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--max-scatters", type=int, default=0)
     ap.add_argument("--device-build", action="store_true", help="build the hierarchy on the GPU (Morton order, balanced tree)")
+    ap.add_argument("--instanced", action="store_true",
+                    help="the two-level workload instead: one 10 008-triangle mesh placed --n-side x --n-side times (100 -> 100 M triangles)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -116,12 +118,20 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = (int(v) for v in args.res.lower().split("x"))
-    half = args.n_side / 2.0
-    prims = S.mixed_field(n_side=args.n_side, seed=0x100000)
-    lights = S.mixed_field_lights(half_extent=half, height=120.0 * half / 500.0, intensity=4000.0 * (half / 500.0) ** 2)
-    camd = S.mixed_field_camera(half_extent=half, res=(W, H))
-    t0 = time.perf_counter()
-    scene = capi.Scene.create(prims, lights, max_leaf=args.max_leaf, on_device=args.device_build)
+    if args.instanced:
+        if args.device_build:
+            raise SystemExit("--instanced scenes are built on the host")
+        prims, instances, lights, camd = S.instanced_field(n_side=args.n_side if args.n_side != 1000 else 100)
+        camd = dict(camd, res=(W, H))
+        t0 = time.perf_counter()
+        scene = capi.Scene.create_instanced(prims, instances, lights, max_leaf=args.max_leaf)
+    else:
+        half = args.n_side / 2.0
+        prims = S.mixed_field(n_side=args.n_side, seed=0x100000)
+        lights = S.mixed_field_lights(half_extent=half, height=120.0 * half / 500.0, intensity=4000.0 * (half / 500.0) ** 2)
+        camd = S.mixed_field_camera(half_extent=half, res=(W, H))
+        t0 = time.perf_counter()
+        scene = capi.Scene.create(prims, lights, max_leaf=args.max_leaf, on_device=args.device_build)
     build_s = time.perf_counter() - t0
     info = scene.info()
     cam = capi.make_camera(**camd)
@@ -214,16 +224,18 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "1M-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
+                "workload": ("%d instances of a %d-triangle mesh (%.1f M triangles, two-level hierarchy), %dx%d, %d mirror bounces, shadow rays to %d point lights"
+                             % (info.n_instances, info.n_prims, info.n_instanced_prims / 1e6, W, H, args.max_scatters, len(lights))) if args.instanced else
+                            "1M-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
                             % (W, H, len(lights)),
-                "n_side": args.n_side, "n_prims": int(info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
+                "n_side": args.n_side, "n_prims": int(info.n_instanced_prims if args.instanced else info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
                 "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
                 "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
-                "shadow_rays": total["shadow_rays"], "scene_build_s": round(build_s, 3),
+                "shadow_rays": total["shadow_rays"], "bounce_rays": total["bounce_rays"], "scene_build_s": round(build_s, 3),
                 "hierarchy": "balanced tree over Morton order, built on the GPU in %.2f ms" % ctx.build_time_ms() if args.device_build
-                             else "binned SAH, built on the host",
+                             else ("binned SAH on the host: one tree over the instances, one per mesh" if args.instanced else "binned SAH, built on the host"),
                 "arithmetic": "FP32 padded-box traversal, FP64 leaf tests and shading",
             },
             "roofline": {
@@ -240,7 +252,7 @@ def main():
                 "prims_per_shadow_ray": c["prims_shadow"] / max(c["shadow_rays"], 1),
             },
         }
-        if world == 1 and args.cpu_seconds > 0 and not args.device_build:
+        if world == 1 and args.cpu_seconds > 0 and not args.device_build and not args.instanced:
             out["cpu_baseline"] = cpu_baseline(scene, prims, lights, camd, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
