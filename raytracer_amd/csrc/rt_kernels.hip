@@ -736,7 +736,7 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
 template <int MODE, bool COUNT, int RECORD, bool INST = false>
-__global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
+__global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVES : RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
