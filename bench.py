@@ -140,6 +140,8 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     ctx.upload(scene)
+    if args.device_build:
+        ctx.upload(scene)          # the first build also loads the builder's code objects: report a build in steady state
 
     tiling = capi.Tiling(W, H, args.tile, world)
     if world == 1:
@@ -192,7 +194,7 @@ def main():
     tm = ctx.timing()
     ctx.set_timing(False)
     # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights and per bounce level
-    kname, k_ms, k_bytes = "k_rays<1,false,0> (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
+    kname, k_ms, k_bytes = ("k_rays<1,false,0,true>" if args.instanced else "k_rays<1,false,0,false>") + " (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
         bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
     stage_ms = {k: tm[k] / args.steps for k in ("primary_ms", "shadow_ms", "resolve_ms", "bounce_ms")}
     t = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cuda")

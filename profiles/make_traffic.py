@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNEL = "k_rays<1, false, 0>"
+KERNEL = "k_rays<1, false, 0, false>"
 
 
 def mean_counter(path, counter):

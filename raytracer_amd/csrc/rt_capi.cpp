@@ -467,13 +467,16 @@ namespace {
 int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
     const uint32_t n = static_cast<uint32_t>(scene->n_slots);
     const size_t total = scene->recs.size();                 // bounded, then unbounded
-    rt_prim_rec* d_in = nullptr; float* d_boxes = nullptr; uint32_t* d_order = nullptr;
+    rt_prim_rec* d_in = nullptr; float* d_boxes = nullptr; uint32_t* d_order = nullptr; void* d_work = nullptr;
+    size_t work_bytes = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int rc = RT_OK;
     auto check = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
     check(hipMalloc(reinterpret_cast<void**>(&d_in), total * sizeof(rt_prim_rec)), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&d_boxes), scene->boxes_f32.size() * sizeof(float)), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&d_order), n * sizeof(uint32_t)), "hipMalloc");
+    if (rc == RT_OK) check(rt_device_build_workspace(n, &work_bytes), "sort workspace");
+    if (rc == RT_OK) check(hipMalloc(&d_work, work_bytes), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_nodes), 2ull * n * sizeof(rt_node32)), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_recs), total * sizeof(rt_prim_rec)), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_slot_prim), total * sizeof(uint32_t)), "hipMalloc");
@@ -489,7 +492,7 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
         check(hipEventCreate(&t0), "hipEventCreate"); check(hipEventCreate(&t1), "hipEventCreate");
         if (rc == RT_OK) {
             (void)hipEventRecord(t0, ctx->stream);
-            check(rt_device_build(ctx->stream, n, d_boxes, bounds, d_in, ctx->d_nodes, ctx->d_recs, d_order), "device build");
+            check(rt_device_build(ctx->stream, n, d_boxes, bounds, d_in, ctx->d_nodes, ctx->d_recs, d_order, d_work, work_bytes), "device build");
             // the unbounded primitives follow the sorted ones unchanged; slot -> id of the sorted part comes from the records
             if (rc == RT_OK && total > n)
                 check(hipMemcpyAsync(ctx->d_recs + n, d_in + n, (total - n) * sizeof(rt_prim_rec), hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
@@ -502,6 +505,7 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
     }
     if (t0) (void)hipEventDestroy(t0);
     if (t1) (void)hipEventDestroy(t1);
+    if (d_work) (void)hipFree(d_work);
     if (d_order) (void)hipFree(d_order);
     if (d_boxes) (void)hipFree(d_boxes);
     if (d_in) (void)hipFree(d_in);

@@ -131,19 +131,40 @@ extern "C" hipError_t rt_launch_slot_ids(hipStream_t st, const rt_prim_rec* recs
     return hipGetLastError();
 }
 
+namespace {
+size_t round256(size_t b) { return (b + 255u) & ~static_cast<size_t>(255u); }
+hipError_t sort_temp_bytes(uint32_t n, size_t& bytes) {
+    unsigned long long* k = nullptr; uint32_t* v = nullptr;
+    bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, n, 0, 63, static_cast<hipStream_t>(nullptr));
+}
+} // namespace
+
+// Device memory the build needs beside its inputs and outputs: two key arrays, one value array, the sort's own scratch.
+extern "C" hipError_t rt_device_build_workspace(uint32_t n, size_t* bytes) {
+    size_t temp = 0;
+    const hipError_t e = sort_temp_bytes(n, temp);
+    *bytes = 2 * round256(sizeof(unsigned long long) * n) + round256(sizeof(uint32_t) * n) + round256(temp ? temp : 16);
+    return e;
+}
+
 // boxes: 6 floats per primitive (lo xyz, hi xyz), already rounded outward; bounds: union of all boxes.
-// nodes_out holds 2 n nodes, recs_out and order_out n entries; all device memory.
+// nodes_out holds 2 n nodes, recs_out and order_out n entries, work rt_device_build_workspace(n) bytes; all device memory.
+// Launches only: nothing is allocated and the stream is not synchronised.
 extern "C" hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* boxes, const float bounds[6], const rt_prim_rec* recs_in,
-                                      rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out) {
+                                      rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out, void* work, size_t work_bytes) {
     if (n == 0) return hipSuccess;
-    unsigned long long *keys_in = nullptr, *keys_out = nullptr; uint32_t* vals_in = nullptr; void* temp = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&keys_in), sizeof(unsigned long long) * n);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&keys_out), sizeof(unsigned long long) * n);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vals_in), sizeof(uint32_t) * n);
     size_t temp_bytes = 0;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, order_out, n, 0, 63, st);
-    if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
-    if (e == hipSuccess) {
+    hipError_t e = sort_temp_bytes(n, temp_bytes);
+    if (e != hipSuccess) return e;
+    const size_t key_bytes = round256(sizeof(unsigned long long) * n), val_bytes = round256(sizeof(uint32_t) * n);
+    if (!work || work_bytes < 2 * key_bytes + val_bytes + round256(temp_bytes ? temp_bytes : 16)) return hipErrorInvalidValue;
+    char* base = static_cast<char*>(work);
+    unsigned long long* keys_in = reinterpret_cast<unsigned long long*>(base);
+    unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
+    uint32_t* vals_in = reinterpret_cast<uint32_t*>(base + 2 * key_bytes);
+    void* temp = base + 2 * key_bytes + val_bytes;
+    {
         // one scale for all three axes (the cube around the scene): a flat scene must not spend curve bits on its thin
         // axis, or the upper levels would cut it into slabs that overlap everywhere
         float ext = 0.0f;
@@ -170,11 +191,5 @@ extern "C" hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* b
             e = hipGetLastError();
         }
     }
-    const hipError_t sync = hipStreamSynchronize(st);       // the temporaries go away below
-    if (e == hipSuccess) e = sync;
-    if (temp) (void)hipFree(temp);
-    if (vals_in) (void)hipFree(vals_in);
-    if (keys_out) (void)hipFree(keys_out);
-    if (keys_in) (void)hipFree(keys_in);
     return e;
 }
