@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--max-leaf", type=int, default=0)
     ap.add_argument("--max-scatters", type=int, default=0)
-    ap.add_argument("--device-build", action="store_true", help="build the hierarchy on the GPU (Morton order, balanced tree)")
+    ap.add_argument("--device-build", action="store_true", help="build the hierarchy on the GPU (Morton order, top-down split)")
     ap.add_argument("--instanced", action="store_true",
                     help="the two-level workload instead: one 10 008-triangle mesh placed --n-side x --n-side times (100 -> 100 M triangles)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 disables it)")
@@ -236,7 +236,7 @@ def main():
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
                 "shadow_rays": total["shadow_rays"], "bounce_rays": total["bounce_rays"], "scene_build_s": round(build_s, 3),
-                "hierarchy": "balanced tree over Morton order, built on the GPU in %.2f ms" % ctx.build_time_ms() if args.device_build
+                "hierarchy": "Morton order cut top-down at the highest differing key bit, built on the GPU in %.2f ms" % ctx.build_time_ms() if args.device_build
                              else ("binned SAH on the host: one tree over the instances, one per mesh" if args.instanced else "binned SAH, built on the host"),
                 "arithmetic": "FP32 padded-box traversal, FP64 leaf tests and shading",
             },

@@ -75,9 +75,10 @@ typedef struct rt_build_opts {
     uint32_t reserved[5];
 } rt_build_opts;
 /* Leave the hierarchy to the GPU: no tree is built on the host, rt_scene_upload sorts the primitives along a Morton
- * curve and builds a balanced tree on the device (about half a millisecond per million primitives, for scenes that change every
- * frame; rays visit more nodes than in the host's SAH tree, results are the same).  rt_scene_get_bvh has nothing to
- * return for such a scene; rt_ctx_download_bvh fetches what the device built. */
+ * curve and cuts the sorted sequence top-down on the device (about a millisecond per million primitives, for scenes that
+ * change every frame; the tree is of the same quality as the host's for evenly spread scenes, results are the same in
+ * any case).  rt_scene_get_bvh has nothing to return for such a scene and rt_scene_info.depth is an upper bound;
+ * rt_ctx_download_bvh fetches what the device built. */
 #define RT_BUILD_ON_DEVICE 1u
 
 typedef struct rt_scene_info {

@@ -1,12 +1,14 @@
-// Hierarchy construction on the GPU: Morton order + a balanced tree of closed-form shape.
+// Hierarchy construction on the GPU: Morton order, then a top-down split along the curve.
 //
 // Takes the place of get_BVH_tree (s2899221/Code/raytracer.cpp:454-499: median split on the largest axis) for scenes
 // that change every frame.  Primitive boxes are sorted along a 63-bit Morton curve of their centroids (rocPRIM radix
-// sort), and the tree over the sorted sequence always halves its range: the node at depth d, position j covers the slots
-// [floor(j n / 2^d), floor((j + 1) n / 2^d)).  Its shape therefore depends on n alone - every index below is a formula,
-// no node is allocated at run time - and its depth is floor(log2 n) + 1, within the traversal stack for any scene the
-// library accepts.  Layout is the one the kernels walk: root at 0, node 1 unused, sibling pairs at even indices, one
-// primitive per leaf.  Boxes are fitted bottom-up, one launch per level.
+// sort).  The tree is then cut level by level: a node over the sorted slots [b, e) splits where the highest bit in
+// which its first and last key differ flips - the spatial median of the octree cell that holds them - unless that
+// would leave too little stack for the larger side, in which case the range is halved (the rule of the host builder:
+// no leaf deeper than RT_STACK_DEPTH - 1).  Nothing is allocated per node: the two children of the node that splits
+// after slot g live at nodes 2 (g + 1) and 2 (g + 1) + 1, and since every inner node has its own g, the 2 n node
+// slots (root, the unused slot beside it, n - 1 pairs) are filled exactly.  Layout is the one the kernels walk: root
+// at 0, sibling pairs at even indices, one primitive per leaf.  Boxes are fitted bottom-up, one launch per level.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -14,27 +16,6 @@
 #include "rt_device.h"
 
 namespace {
-
-struct Shape {
-    uint32_t n;          // leaves
-    uint32_t full;       // d*: deepest level whose 2^d nodes all exist (every node there covers 1 or 2 slots)
-    uint32_t last_base;  // index of the first node of level d* + 1
-};
-
-__host__ __device__ inline Shape shape_of(uint32_t n) {
-    Shape s; s.n = n; s.full = 0;
-    while ((2u << s.full) <= n) ++s.full;           // floor(log2 n)
-    s.last_base = 2u << s.full;                     // levels 1..d* occupy [2, 2^(d*+1))
-    return s;
-}
-
-// first slot of the node at depth d, position j
-__host__ __device__ inline uint32_t slot_begin(uint32_t n, uint32_t d, uint32_t j) {
-    return static_cast<uint32_t>((static_cast<unsigned long long>(j) * n) >> d);
-}
-
-// index of the node at depth d <= d*, position j (root: 0; level d >= 1 starts at 2^d)
-__host__ __device__ inline uint32_t node_index(uint32_t d, uint32_t j) { return d == 0 ? 0u : (1u << d) + j; }
 
 __device__ inline unsigned long long spread21(unsigned long long v) {     // 21 bits -> every third bit
     v &= 0x1FFFFFull;
@@ -80,42 +61,71 @@ __device__ inline void store_leaf(rt_node32* nodes, uint32_t index, const float*
     nodes[index] = nd;
 }
 
-// Level d* + 1 (children of the two-slot nodes of level d*) and the one-slot nodes of level d*: all leaves.
-__global__ void __launch_bounds__(256) k_leaves(Shape s, const float* __restrict__ boxes, const uint32_t* __restrict__ order,
-                                                rt_node32* __restrict__ nodes) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= (1u << s.full)) return;
-    const uint32_t b = slot_begin(s.n, s.full, j), e = slot_begin(s.n, s.full, j + 1);
-    if (e - b == 1) { store_leaf(nodes, node_index(s.full, j), boxes, order, b); return; }
-    // two slots: this node is internal; its pair sits at last_base + 2 * (two-slot nodes before j) = last_base + 2 (b - j)
-    const uint32_t pair = s.last_base + 2u * (b - j);
-    store_leaf(nodes, pair, boxes, order, b);
-    store_leaf(nodes, pair + 1, boxes, order, b + 1);
+constexpr uint32_t kLevels = RT_STACK_DEPTH - 1;       // inner nodes live at depths 0 .. kLevels - 1
+constexpr uint32_t kSplitBlocks = 512;
+
+__device__ inline uint32_t ceil_log2(uint32_t m) { return m <= 1u ? 0u : 32u - static_cast<uint32_t>(__clz(m - 1u)); }
+
+// One level of the top-down cut.  items[off[level] .. +cnt[level]) are this level's inner nodes as (node, b, e, -);
+// children that are inner nodes themselves are appended to the next level's run, single slots become leaves at once.
+__global__ void __launch_bounds__(256) k_split_level(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ order,
+                                                     const float* __restrict__ boxes, uint32_t level, uint4* __restrict__ items,
+                                                     uint32_t* __restrict__ off, uint32_t* __restrict__ cnt, rt_node32* __restrict__ nodes) {
+    const uint32_t begin = off[level], count = cnt[level], next = begin + count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[level + 1] = next;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint4 it = items[begin + i];
+        const uint32_t b = it.y, e = it.z, m = e - b;
+        bool halve = level + ceil_log2(m) >= kLevels;
+        uint32_t g = 0;                                     // last slot of the left child
+        if (!halve) {
+            const unsigned long long first = keys[b], last = keys[e - 1];
+            if (first == last) halve = true;
+            else {
+                const unsigned long long bit = 1ull << (63 - __clzll(static_cast<long long>(first ^ last)));
+                uint32_t lo = b, hi = e - 1;                // keys[lo] has the bit clear, keys[hi] has it set
+                while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (keys[mid] & bit) hi = mid; else lo = mid; }
+                g = lo;
+                const uint32_t big = (g + 1u - b > e - 1u - g) ? g + 1u - b : e - 1u - g;
+                if (level + 1u + ceil_log2(big) > kLevels) halve = true;
+            }
+        }
+        if (halve) g = b + (m + 1u) / 2u - 1u;
+        const uint32_t pair = 2u * (g + 1u);
+        nodes[it.x].first = pair; nodes[it.x].count = 0;
+#pragma unroll
+        for (uint32_t side = 0; side < 2u; ++side) {
+            const uint32_t cb = side ? g + 1u : b, ce = side ? e : g + 1u;
+            if (ce - cb == 1u) store_leaf(nodes, pair + side, boxes, order, cb);
+            else items[next + atomicAdd(&cnt[level + 1], 1u)] = make_uint4(pair + side, cb, ce, 0u);
+        }
+    }
 }
 
-// Internal nodes of one level: box = union of the two children, which are already in place.
-__global__ void __launch_bounds__(256) k_fit_level(Shape s, uint32_t d, rt_node32* __restrict__ nodes) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= (1u << d)) return;
-    uint32_t pair;
-    if (d == s.full) {
-        const uint32_t b = slot_begin(s.n, d, j), e = slot_begin(s.n, d, j + 1);
-        if (e - b < 2) return;                      // a leaf of this level, written by k_leaves
-        pair = s.last_base + 2u * (b - j);
-    } else {
-        pair = node_index(d + 1, 2u * j);
+// Boxes of one level's inner nodes: the union of the two children, which are already in place.
+__global__ void __launch_bounds__(256) k_fit_level(uint32_t level, const uint4* __restrict__ items, const uint32_t* __restrict__ off,
+                                                   const uint32_t* __restrict__ cnt, rt_node32* __restrict__ nodes) {
+    const uint32_t begin = off[level], count = cnt[level];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t node = items[begin + i].x;
+        const uint32_t pair = nodes[node].first;
+        const rt_node32 l = nodes[pair], r = nodes[pair + 1];
+        for (int k = 0; k < 3; ++k) { nodes[node].lo[k] = fminf(l.lo[k], r.lo[k]); nodes[node].hi[k] = fmaxf(l.hi[k], r.hi[k]); }
     }
-    const rt_node32 l = nodes[pair], r = nodes[pair + 1];
-    rt_node32 nd;
-    for (int k = 0; k < 3; ++k) { nd.lo[k] = fminf(l.lo[k], r.lo[k]); nd.hi[k] = fmaxf(l.hi[k], r.hi[k]); }
-    nd.first = pair; nd.count = 0;
-    nodes[node_index(d, j)] = nd;
+}
+
+__global__ void k_first_item(uint32_t n, uint4* items, uint32_t* off, uint32_t* cnt) {
+    for (uint32_t k = 0; k <= kLevels + 1u; ++k) { off[k] = 0; cnt[k] = 0; }
+    items[0] = make_uint4(0u, 0u, n, 0u);
+    cnt[0] = 1;
 }
 
 __global__ void __launch_bounds__(256) k_slot_ids(const rt_prim_rec* __restrict__ recs, uint32_t n, uint32_t* __restrict__ slot_prim) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) slot_prim[i] = recs[i].id;
 }
+
+__global__ void k_root_leaf(const float* boxes, const uint32_t* order, rt_node32* nodes) { store_leaf(nodes, 0, boxes, order, 0); }
 
 __global__ void k_pad_node(rt_node32* nodes) {      // the unused slot beside the root: an inverted box
     rt_node32 nd;
@@ -144,7 +154,8 @@ hipError_t sort_temp_bytes(uint32_t n, size_t& bytes) {
 extern "C" hipError_t rt_device_build_workspace(uint32_t n, size_t* bytes) {
     size_t temp = 0;
     const hipError_t e = sort_temp_bytes(n, temp);
-    *bytes = 2 * round256(sizeof(unsigned long long) * n) + round256(sizeof(uint32_t) * n) + round256(temp ? temp : 16);
+    *bytes = 2 * round256(sizeof(unsigned long long) * n) + round256(sizeof(uint32_t) * n) + round256(temp ? temp : 16)
+           + round256(sizeof(uint4) * n) + round256(sizeof(uint32_t) * 2 * (kLevels + 2));
     return e;
 }
 
@@ -158,12 +169,17 @@ extern "C" hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* b
     hipError_t e = sort_temp_bytes(n, temp_bytes);
     if (e != hipSuccess) return e;
     const size_t key_bytes = round256(sizeof(unsigned long long) * n), val_bytes = round256(sizeof(uint32_t) * n);
-    if (!work || work_bytes < 2 * key_bytes + val_bytes + round256(temp_bytes ? temp_bytes : 16)) return hipErrorInvalidValue;
+    const size_t sort_bytes = round256(temp_bytes ? temp_bytes : 16), item_bytes = round256(sizeof(uint4) * n);
+    if (!work || work_bytes < 2 * key_bytes + val_bytes + sort_bytes + item_bytes + round256(sizeof(uint32_t) * 2 * (kLevels + 2)))
+        return hipErrorInvalidValue;
     char* base = static_cast<char*>(work);
     unsigned long long* keys_in = reinterpret_cast<unsigned long long*>(base);
     unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
     uint32_t* vals_in = reinterpret_cast<uint32_t*>(base + 2 * key_bytes);
     void* temp = base + 2 * key_bytes + val_bytes;
+    uint4* items = reinterpret_cast<uint4*>(base + 2 * key_bytes + val_bytes + sort_bytes);
+    uint32_t* off = reinterpret_cast<uint32_t*>(base + 2 * key_bytes + val_bytes + sort_bytes + item_bytes);
+    uint32_t* cnt = off + (kLevels + 2);
     {
         // one scale for all three axes (the cube around the scene): a flat scene must not spend curve bits on its thin
         // axis, or the upper levels would cut it into slabs that overlap everywhere
@@ -178,14 +194,16 @@ extern "C" hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* b
         if (e == hipSuccess) {
             const size_t pieces = static_cast<size_t>(n) * 10u;
             hipLaunchKernelGGL(k_permute_records, dim3(static_cast<uint32_t>((pieces + 255u) / 256u)), dim3(256), 0, st, recs_in, order_out, n, recs_out);
-            const Shape s = shape_of(n);
             if (n == 1) {
                 // a single primitive: the root is its leaf
-                hipLaunchKernelGGL(k_leaves, dim3(1), dim3(256), 0, st, s, boxes, order_out, nodes_out);
+                hipLaunchKernelGGL(k_root_leaf, dim3(1), dim3(1), 0, st, boxes, order_out, nodes_out);
             } else {
-                hipLaunchKernelGGL(k_leaves, dim3(((1u << s.full) + 255u) / 256u), dim3(256), 0, st, s, boxes, order_out, nodes_out);
-                for (uint32_t d = s.full + 1; d-- > 0;)
-                    hipLaunchKernelGGL(k_fit_level, dim3(((1u << d) + 255u) / 256u), dim3(256), 0, st, s, d, nodes_out);
+                const uint32_t blocks_l = (n / 2u + 255u) / 256u < kSplitBlocks ? (n / 2u + 255u) / 256u : kSplitBlocks;
+                hipLaunchKernelGGL(k_first_item, dim3(1), dim3(1), 0, st, n, items, off, cnt);
+                for (uint32_t level = 0; level < kLevels; ++level)
+                    hipLaunchKernelGGL(k_split_level, dim3(blocks_l), dim3(256), 0, st, keys_out, order_out, boxes, level, items, off, cnt, nodes_out);
+                for (uint32_t level = kLevels; level-- > 0;)
+                    hipLaunchKernelGGL(k_fit_level, dim3(blocks_l), dim3(256), 0, st, level, items, off, cnt, nodes_out);
             }
             hipLaunchKernelGGL(k_pad_node, dim3(1), dim3(1), 0, st, nodes_out);
             e = hipGetLastError();

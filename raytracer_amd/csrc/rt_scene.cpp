@@ -6,13 +6,13 @@
 
 #include "rt_scene.h"
 
-// Shape of the tree the device builds over n primitives (rt_gpu_build.hip): it halves its range at every node, so it has
-// 2 n node slots (root, the unused slot beside it, 2 n - 2 others) and depth ceil(log2 n).
+// Size of the tree the device builds over n primitives (rt_gpu_build.hip): one primitive per leaf, so 2 n node slots
+// (root, the unused slot beside it, n - 1 sibling pairs); its depth depends on the data and is bounded like the host
+// builder's.
 static uint32_t rt_device_build_node_count(uint32_t n) { return n ? 2u * n : 0u; }
 static uint32_t rt_device_build_depth(uint32_t n) {
-    uint32_t d = 0;
-    while ((1ull << d) < n) ++d;
-    return d;
+    if (n <= 1) return 0;
+    return n - 1 < RT_STACK_DEPTH - 1 ? n - 1 : RT_STACK_DEPTH - 1;
 }
 
 // Two-level scene: one tree per distinct mesh (a run of the primitive pool), one tree over the instances' world boxes.

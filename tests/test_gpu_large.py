@@ -193,7 +193,7 @@ def test_device_built_hierarchy_at_a_million_primitives(ctx):
     ctx.upload(host)
     want_rgb, want_ids = ctx.render(cam, max_scatters=0, want_ids=True)
     dev = capi.Scene.create(prims, lights, on_device=True)
-    assert dev.info().depth == 21 and dev.info().n_nodes == 2 * dev.info().n_slots
+    assert dev.info().depth <= 31 and dev.info().n_nodes == 2 * dev.info().n_slots
     ctx.upload(dev)
     assert 0.0 < ctx.build_time_ms() < 100.0
     rgb, ids = ctx.render(cam, max_scatters=0, want_ids=True)
