@@ -188,7 +188,7 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
     rt_bvh_result bvh;
     s->device_build = opts && (opts->flags & RT_BUILD_ON_DEVICE);
     s->boxes_f32.clear();
-    if (s->device_build && boxes.size() > 16) {
+    if (boxes.size() > 16) {
         // A balanced tree over a space-filling curve has no good place for a primitive that spans a large part of the
         // scene (a ground plane): every ancestor of its leaf would span the scene too, and every ray would walk that
         // chain.  Up to 8 such primitives are set beside the tree and tested against every ray instead.
