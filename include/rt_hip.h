@@ -84,7 +84,8 @@ typedef struct rt_build_opts {
 typedef struct rt_scene_info {
     uint64_t n_prims;         /* primitives in id order */
     uint64_t n_slots;         /* primitives reachable through the BVH */
-    uint64_t n_loose;         /* primitives tested against every ray (unbounded: a zero / non-finite scale) */
+    uint64_t n_loose;         /* primitives tested against every ray: unbounded ones (a zero / non-finite scale) and, in
+                                 scenes of more than 16, up to 8 that span a quarter of the scene or more */
     uint32_t n_nodes, depth;
     uint32_t n_lights, n_cameras;
     uint32_t n_by_kind[8];
