@@ -23,6 +23,9 @@
 #include "rt_device.h"
 
 #define DEV __device__ __forceinline__
+#ifndef RT_INNER_EXIT_REL
+#define RT_INNER_EXIT_REL 4          // 0: lanes wait until every ray of the wave has left the inner nodes
+#endif
 
 namespace {
 
@@ -866,8 +869,20 @@ __global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVE
         }
         // ---- one while-while round for the rays in flight ----------------------------------------------------------
         if (state == TRAV) {
+            // Lanes step through inner nodes together; once fewer than a quarter of the rays in flight are still among
+            // inner nodes the others test their leaves, and the stragglers resume in the next round (they would
+            // otherwise hold three quarters of the wave idle; measured 10.96 -> 10.03 ms per frame on the 1.3 M scene).
+#if RT_INNER_EXIT_REL > 0
+            const int in_flight = __popcll(__ballot(true));
+            while (w.at_internal()) {
+                w.step_internal(sc);
+                if (__popcll(__ballot(w.at_internal())) * RT_INNER_EXIT_REL < in_flight) break;
+            }
+            if (!w.done() && !w.at_internal()) w.step_leaf(sc);
+#else
             while (w.at_internal()) w.step_internal(sc);
             if (!w.done()) w.step_leaf(sc);
+#endif
             if (w.done()) state = DONE;
         }
     }
