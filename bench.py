@@ -243,6 +243,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # what actually crossed the fabric, per second: the algorithmic figure above counts every node and record a
+                # ray fetches, and most of those fetches are served by L1 / L2, so it can exceed the HBM peak
+                "hbm_side_achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None,
+                "hbm_side_frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                 "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,
                 "algorithmic_bytes_per_launch": k_bytes,
                 "stage_ms_per_frame": stage_ms,
