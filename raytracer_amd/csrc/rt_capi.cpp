@@ -598,16 +598,17 @@ uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
 
 // Carve the frame working set out of the context's grow-only scratch (allocated on first use of a size).
 int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
-    const size_t planes = 7 + n_batch;
+    const size_t planes = 7;
     void* base = nullptr;
-    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t) + sizeof(uint32_t)) + 256, &base)) return rc;
+    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t) + sizeof(uint32_t) + n_batch) + 256, &base)) return rc;
     double* d = static_cast<double*>(base);
     fb.px = d; fb.py = d + n; fb.pz = d + 2*n; fb.nx = d + 3*n; fb.ny = d + 4*n; fb.nz = d + 5*n;
-    fb.lighting = d + 6*n; fb.contrib = d + 7*n;
+    fb.lighting = d + 6*n;
     fb.id = reinterpret_cast<int32_t*>(d + planes * n);
     fb.n = n;
     fb.ray = nullptr; fb.rawn = nullptr; fb.alive = nullptr; fb.level = 0;
     fb.albedo = ctx->sc.n_textures ? reinterpret_cast<uint32_t*>(fb.id + n) : nullptr;
+    fb.lit = reinterpret_cast<uint8_t*>(fb.id + 2 * n);
     return RT_OK;
 }
 
@@ -652,7 +653,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
                                     ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
             ctx->mark_end();
             ctx->mark_begin(2);
-            RT_HIP(rt_launch_bounce_resolve(ctx->stream, &ctx->sc, &fb, &lv, nb, l0 == 0, l0 + nb >= n_lights, max_scatters,
+            RT_HIP(rt_launch_bounce_resolve(ctx->stream, &ctx->sc, &dc, &fb, &lv, l0, nb, l0 == 0, l0 + nb >= n_lights, max_scatters,
                                             min_scatter_intensity));
             ctx->mark_end();
         }
@@ -687,7 +688,7 @@ int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t 
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
         ctx->mark_end();
         ctx->mark_begin(2);
-        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &fb, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
+        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &dc, &fb, l0, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
         ctx->mark_end();
     }
     return RT_OK;

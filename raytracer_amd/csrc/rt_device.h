@@ -10,7 +10,7 @@
 #endif
 #define RT_CTR_SHARDS 64           // counter replicas, one cache line each, summed on read
 #define RT_CTR_STRIDE 16           // 64-bit words between replicas (128 bytes)
-#define RT_LIGHT_BATCH 8           // lights per shadow launch (bounds the contribution planes)
+#define RT_LIGHT_BATCH 8           // lights per shadow launch (bounds the verdict planes)
 #ifndef RT_RAYS_MIN_WAVES
 #define RT_RAYS_MIN_WAVES 4        // waves per SIMD the persistent kernel is compiled for (caps VGPRs at 128)
 #endif
@@ -59,7 +59,7 @@ struct FrameBufs {
     double *px, *py, *pz;          // hit point
     double *nx, *ny, *nz;          // unit normal, re-normalised as RayTracer::shade does
     double *lighting;              // running light sum between light batches
-    double *contrib;               // [light in batch][n] this light's term
+    uint8_t *lit;                  // [light in batch][n] 1 = the light reaches the point (shadow verdict)
     int32_t *id;                   // primary hit id, -1 = miss / padding
     size_t n;
     // Mirror-bounce frames only (null otherwise): the chain of trace_ray_recursive is walked level by level.
@@ -87,7 +87,8 @@ hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera
 hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                             uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
-hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, uint32_t n_batch, int first, int last, uint8_t* rgb);
+hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, uint32_t light0, uint32_t n_batch,
+                             int first, int last, uint8_t* rgb);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr);
 hipError_t rt_launch_accumulate(hipStream_t st, const uint8_t* rgb, uint32_t* acc, size_t n, int first);
@@ -95,8 +96,8 @@ hipError_t rt_launch_finish_samples(hipStream_t st, const uint32_t* acc, size_t 
 hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec* rec, const double* rays, uint64_t n, double* records);
 hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
                                 uint8_t* rgb, rt_counters* ctr);
-hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, const LevelBufs* lv, uint32_t n_batch,
-                                    int first, int last, int max_scatters, double min_si);
+hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, const LevelBufs* lv,
+                                    uint32_t light0, uint32_t n_batch, int first, int last, int max_scatters, double min_si);
 hipError_t rt_launch_bounce_fold(hipStream_t st, const DevScene* sc, const LevelBufs* lv, size_t n, uint8_t* rgb);
 hipError_t rt_device_build_workspace(uint32_t n, size_t* bytes);
 hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* boxes, const float bounds[6], const rt_prim_rec* recs_in,

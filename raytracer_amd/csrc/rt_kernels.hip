@@ -16,7 +16,7 @@
 // then all leaf tests run together - FP64 leaf code is 10-40x a box test, so it must not run lane by lane.
 // The frame pipeline for max_scatters = 0 is three launches: k_primary (closest hit, surface record per
 // pixel), k_shadow (one wave per (tile, light): all lanes aim at the same light), k_resolve (sum the light
-// contributions in light order, ambient, albedo, gamma).
+// terms of the lights that reach each point in light order, ambient, albedo, gamma).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -784,19 +784,9 @@ __global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVE
                         }
                     }
                 } else {
-                    double c = 0.0;
+                    // only the verdict leaves this kernel: the light's term is evaluated by the resolve kernels, densely
                     const uint32_t lj = (ridx >> 6) / n_tiles;
-                    if (!w.blocked()) {
-                        const rt_light L = sc.lights[light0 + lj];
-                        const rt_mat_rec m = sc.mats[fb.id[out]];
-                        // the view vector points at the origin of the ray that found this surface (raytracer.cpp:185-186)
-                        double vox = cam.pos[0], voy = cam.pos[1], voz = cam.pos[2];
-                        if (fb.ray && fb.level > 0) { vox = fb.ray[out]; voy = fb.ray[fb.n + out]; voz = fb.ray[2*fb.n + out]; }
-                        const RayD& sr = INST ? w.rw : w.r;
-                        c = light_value(L, m, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out],
-                                        sr.dx, sr.dy, sr.dz, vox, voy, voz);
-                    }
-                    fb.contrib[static_cast<size_t>(lj) * fb.n + out] = c;
+                    fb.lit[static_cast<size_t>(lj) * fb.n + out] = w.blocked() ? 0 : 1;
                 }
                 state = IDLE;
             }
@@ -898,9 +888,23 @@ __global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVE
     }
 }
 
-// Sum the light terms in light order (the reference's accumulation order), then ambient, albedo, gamma.
-// Lights beyond one batch: the running sum is parked in fb.lighting between batches.
-__global__ void __launch_bounds__(256) k_resolve(DevScene sc, FrameBufs fb, uint32_t n_batch, int first, int last,
+// The terms of the lights of one batch that reach surface point i, added in light order (the reference's accumulation
+// order, raytracer.cpp:210-260) to `lighting`.  view = origin of the ray that found the surface (raytracer.cpp:185-186).
+DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
+                          double vox, double voy, double voz, double lighting) {
+    const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
+    for (uint32_t j = 0; j < n_batch; ++j) {
+        if (!fb.lit[static_cast<size_t>(j) * fb.n + i]) continue;
+        const rt_light L = sc.lights[light0 + j];
+        double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
+        lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, vox, voy, voz);
+    }
+    return lighting;
+}
+
+// Light terms, then ambient, albedo, gamma.  Lights beyond one batch: the running sum is parked in fb.lighting between
+// batches.
+__global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, FrameBufs fb, uint32_t light0, uint32_t n_batch, int first, int last,
                                                  uint8_t* __restrict__ rgb) {
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= fb.n) return;
@@ -909,10 +913,9 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, FrameBufs fb, uint
         if (last) { rgb[i*3] = sc.gamma[0]; rgb[i*3 + 1] = sc.gamma[0]; rgb[i*3 + 2] = sc.gamma[0]; }
         return;
     }
-    double lighting = first ? 0.0 : fb.lighting[i];
-    for (uint32_t j = 0; j < n_batch; ++j) lighting += fb.contrib[static_cast<size_t>(j) * fb.n + i];
-    if (!last) { fb.lighting[i] = lighting; return; }
     const rt_mat_rec m = sc.mats[id];
+    const double lighting = add_lit_lights(sc, fb, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], first ? 0.0 : fb.lighting[i]);
+    if (!last) { fb.lighting[i] = lighting; return; }
     const uint32_t c = finish_shade(m, fb.albedo ? fb.albedo[i] : solid_albedo(m), lighting);
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
 }
@@ -1022,7 +1025,7 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
 // Mirror bounces (trace_ray_recursive, raytracer.cpp:281-371) as a level-by-level pipeline: each level is traced and
 // shadow-tested by the same ray kernels as a plain frame; this kernel closes a level - local colour, Fresnel weight,
 // tint, and the ray of the next level - and k_bounce_fold blends the levels back up once the chain has ended.
-__global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, FrameBufs fb, LevelBufs lv, uint32_t n_batch, int first, int last,
+__global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, DevCamera cam, FrameBufs fb, LevelBufs lv, uint32_t light0, uint32_t n_batch, int first, int last,
                                                         int max_scatters, double min_scatter_intensity) {
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= fb.n) return;
@@ -1031,10 +1034,11 @@ __global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, FrameBufs f
     const int32_t id = fb.id[i];
     uint32_t local = 0;
     if (id >= 0) {
-        double lighting = first ? 0.0 : fb.lighting[i];
-        for (uint32_t j = 0; j < n_batch; ++j) lighting += fb.contrib[static_cast<size_t>(j) * fb.n + i];
-        if (!last) { fb.lighting[i] = lighting; return; }
         const rt_mat_rec m0 = sc.mats[id];
+        double vox = cam.pos[0], voy = cam.pos[1], voz = cam.pos[2];
+        if (level > 0) { vox = fb.ray[i]; voy = fb.ray[fb.n + i]; voz = fb.ray[2*fb.n + i]; }
+        const double lighting = add_lit_lights(sc, fb, i, light0, n_batch, m0, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
+        if (!last) { fb.lighting[i] = lighting; return; }
         local = finish_shade(m0, fb.albedo ? fb.albedo[i] : solid_albedo(m0), lighting);
     } else if (!last) return;
     lv.local[static_cast<size_t>(level) * fb.n + i] = local;
@@ -1186,10 +1190,10 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, uint32_t n_batch, int first, int last,
-                                        uint8_t* rgb) {
+extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, uint32_t light0,
+                                        uint32_t n_batch, int first, int last, uint8_t* rgb) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
-    if (nb) hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *fb, n_batch, first, last, rgb);
+    if (nb) hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *fb, light0, n_batch, first, last, rgb);
     return hipGetLastError();
 }
 
@@ -1231,10 +1235,10 @@ extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, c
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const FrameBufs* fb, const LevelBufs* lv, uint32_t n_batch,
-                                               int first, int last, int max_scatters, double min_si) {
+extern "C" hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, const LevelBufs* lv,
+                                               uint32_t light0, uint32_t n_batch, int first, int last, int max_scatters, double min_si) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
-    if (nb) hipLaunchKernelGGL(k_bounce_resolve, dim3(nb), dim3(256), 0, st, *sc, *fb, *lv, n_batch, first, last, max_scatters, min_si);
+    if (nb) hipLaunchKernelGGL(k_bounce_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *fb, *lv, light0, n_batch, first, last, max_scatters, min_si);
     return hipGetLastError();
 }
 
