@@ -600,7 +600,7 @@ uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
 int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
     const size_t planes = 7;
     void* base = nullptr;
-    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t) + sizeof(uint32_t) + n_batch) + 256, &base)) return rc;
+    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + n_batch) + 256, &base)) return rc;
     double* d = static_cast<double*>(base);
     fb.px = d; fb.py = d + n; fb.pz = d + 2*n; fb.nx = d + 3*n; fb.ny = d + 4*n; fb.nz = d + 5*n;
     fb.lighting = d + 6*n;
@@ -608,7 +608,8 @@ int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
     fb.n = n;
     fb.ray = nullptr; fb.rawn = nullptr; fb.alive = nullptr; fb.level = 0;
     fb.albedo = ctx->sc.n_textures ? reinterpret_cast<uint32_t*>(fb.id + n) : nullptr;
-    fb.lit = reinterpret_cast<uint8_t*>(fb.id + 2 * n);
+    fb.slot = reinterpret_cast<uint32_t*>(fb.id + 2 * n); fb.inst = fb.slot + n;
+    fb.lit = reinterpret_cast<uint8_t*>(fb.id + 4 * n);
     return RT_OK;
 }
 

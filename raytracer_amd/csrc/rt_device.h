@@ -60,7 +60,8 @@ struct FrameBufs {
     double *nx, *ny, *nz;          // unit normal, re-normalised as RayTracer::shade does
     double *lighting;              // running light sum between light batches
     uint8_t *lit;                  // [light in batch][n] 1 = the light reaches the point (shadow verdict)
-    int32_t *id;                   // primary hit id, -1 = miss / padding
+    int32_t *id;                   // primitive whose material applies to the hit, -1 = miss / padding
+    uint32_t *slot, *inst;         // what the closest-hit launch found: record slot (all ones = nothing), instance slot
     size_t n;
     // Mirror-bounce frames only (null otherwise): the chain of trace_ray_recursive is walked level by level.
     double *ray;                   // 6 planes: origin xyz, direction xyz of the ray traced at this level

@@ -503,7 +503,7 @@ DEV void best_record(const DevScene& sc, const Best& b, const RayD& world_ray, H
         mat_id = static_cast<int32_t>(tag.y);
     } else {
         hit_record<true, UV>(rec, tag.x, world_ray, h);
-        mat_id = b.id;
+        mat_id = static_cast<int32_t>(tag.y);
     }
 }
 
@@ -732,10 +732,10 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 // counter), then the wave advances all its walks by one while-while round.  Finished lanes are only swapped once
 // RT_REFILL_MIN of them have piled up, so that the result / set-up code also runs on a well-filled wave.
 // MODE 0 - closest hits: ray i = lane (i % 64) of tile (i / 64) of the pixel map; writes ids / dist (optional) and,
-//          with RECORD != 0, the surface record (point, re-normalised normal, id) the shadow pass starts from.
-//          RECORD & 2: a level of a mirror-bounce frame - level 0 also stores its camera rays, deeper levels take
-//          their rays from the slots (left there by k_bounce_resolve), and the raw normal is kept for the Fresnel term.
-//          RECORD & 4: the scene has textures - the albedo under the hit's (u, v) is stored with the record.
+//          with RECORD != 0, the record slot that was hit (and the instance), from which k_surface makes the
+//          surface record the shadow pass starts from.
+//          RECORD & 2: a level of a mirror-bounce frame - deeper levels take their rays from the slots (left there by
+//          k_bounce_resolve).
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
 template <int MODE, bool COUNT, int RECORD, bool INST = false>
@@ -770,18 +770,9 @@ __global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVE
                     if (ids) ids[out] = w.best.id;
                     if (dist) dist[out] = w.best.dist;
                     if (RECORD) {
-                        // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
-                        int32_t mat_id = -1;
-                        HitD h;
-                        if (hit) best_record<(RECORD & 4) != 0, INST>(sc, w.best, INST ? w.rw : w.r, h, mat_id);
-                        fb.id[out] = mat_id;
-                        if (hit) {
-                            if (RECORD & 4) fb.albedo[out] = albedo_at(sc, sc.mats[mat_id], h.u, h.v);
-                            double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
-                            fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
-                            fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
-                            if (RECORD & 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
-                        }
+                        // which record was hit (and in which instance); k_surface turns that into the surface record
+                        fb.slot[out] = w.best.slot;
+                        if (INST) fb.inst[out] = w.best.inst;
                     }
                 } else {
                     // only the verdict leaves this kernel: the light's term is evaluated by the resolve kernels, densely
@@ -829,13 +820,9 @@ __global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVE
                                     r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
                                     r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
                                     r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
-                                } else { have = false; fb.id[out] = -1; }
+                                } else { have = false; fb.slot[out] = REF_NONE; }
                             } else {
                                 primary_ray(cam, p.x, p.y, r);
-                                if (RECORD & 2) {
-                                    fb.ray[out] = r.ox; fb.ray[fb.n + out] = r.oy; fb.ray[2*fb.n + out] = r.oz;
-                                    fb.ray[3*fb.n + out] = r.dx; fb.ray[4*fb.n + out] = r.dy; fb.ray[5*fb.n + out] = r.dz;
-                                }
                             }
                             if (have) {
                                 w.start(sc, r, my_stack, deep.e, 0.0);
@@ -886,6 +873,46 @@ __global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVE
         add_counter(ctr, shard, F_SHADOW, n_cast);
         if (COUNT) { add_counter(ctr, shard, F_VN_S, w.vn); add_counter(ctr, shard, F_VP_S, w.vp); }
     }
+}
+
+// Surface records for the hits of a closest-hit launch, densely: one lane per pixel of the pixel map re-creates its ray
+// (camera ray, or the ray k_bounce_resolve left for this level), evaluates the winning primitive in full (point,
+// normal; surface coordinates and albedo when the scene has textures) and stores what the shadow and resolve passes read.
+// FLAGS & 2: a level of a mirror-bounce frame (keeps the raw normal, and at level 0 the camera ray, for the Fresnel
+// term and the next level); FLAGS & 4: textures.
+template <int FLAGS, bool INST>
+__global__ void __launch_bounds__(256) k_surface(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, FrameBufs fb) {
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= n_tiles) return;
+    const Pixel p = map_pixel(pm, g, threadIdx.x & 63u);
+    if (!p.valid) return;
+    const uint32_t out = p.out;
+    const uint32_t slot = fb.slot[out];
+    RayD r;
+    if ((FLAGS & 2) && fb.level > 0) {
+        if (slot == REF_NONE) { fb.id[out] = -1; return; }          // no ray here, or a miss
+        r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
+        r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
+        r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
+    } else {
+        primary_ray(cam, p.x, p.y, r);
+        if (FLAGS & 2) {
+            fb.ray[out] = r.ox; fb.ray[fb.n + out] = r.oy; fb.ray[2*fb.n + out] = r.oz;
+            fb.ray[3*fb.n + out] = r.dx; fb.ray[4*fb.n + out] = r.dy; fb.ray[5*fb.n + out] = r.dz;
+        }
+        if (slot == REF_NONE) { fb.id[out] = -1; return; }
+    }
+    Best b; b.dist = 0.0; b.slot = slot; b.id = 0; b.inst = INST ? fb.inst[out] : REF_NONE;
+    HitD h; h.u = 0.0; h.v = 0.0;
+    int32_t mat_id = -1;
+    best_record<(FLAGS & 4) != 0, INST>(sc, b, r, h, mat_id);
+    // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
+    fb.id[out] = mat_id;
+    if (FLAGS & 4) fb.albedo[out] = albedo_at(sc, sc.mats[mat_id], h.u, h.v);
+    double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
+    fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
+    fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
+    if (FLAGS & 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
 }
 
 // The terms of the lights of one batch that reach surface point i, added in light order (the reference's accumulation
@@ -1149,29 +1176,35 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
     const FrameBufs none{};
     const uint32_t n_rays = n_tiles * 64u;
     const dim3 grid(n_waves), block(64);
-    const int variant = !fb ? 0 : (1 | (fb->ray ? 2 : 0) | (fb->albedo ? 4 : 0));
+    const int variant = !fb ? 0 : (1 | (fb->ray ? 2 : 0));
+    const int flags = !fb ? 0 : (variant | (fb->albedo ? 4 : 0));
 #define RT_LAUNCH_PRIMARY_I(R, FB, I)                                                                                                    \
     do {                                                                                                                                 \
         if (counting) hipLaunchKernelGGL((k_rays<0, true, R, I>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min);  \
         else          hipLaunchKernelGGL((k_rays<0, false, R, I>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
     } while (0)
-#define RT_LAUNCH_PRIMARY(R, FB) RT_LAUNCH_PRIMARY_I(R, FB, false)
+#define RT_LAUNCH_SURFACE(F, I) hipLaunchKernelGGL((k_surface<F, I>), dim3((n_tiles + 3u) / 4u), dim3(256), 0, st, *sc, *cam, *pm, n_tiles, *fb)
     if (sc->inst) {                     // two-level scene (no textures there)
         switch (variant) {
             case 0: RT_LAUNCH_PRIMARY_I(0, none, true); break;
-            case 1: RT_LAUNCH_PRIMARY_I(1, *fb, true); break;
-            default: RT_LAUNCH_PRIMARY_I(3, *fb, true); break;
+            case 1: RT_LAUNCH_PRIMARY_I(1, *fb, true); RT_LAUNCH_SURFACE(1, true); break;
+            default: RT_LAUNCH_PRIMARY_I(3, *fb, true); RT_LAUNCH_SURFACE(3, true); break;
         }
         return hipGetLastError();
     }
     switch (variant) {
-        case 0: RT_LAUNCH_PRIMARY(0, none); break;
-        case 1: RT_LAUNCH_PRIMARY(1, *fb); break;
-        case 3: RT_LAUNCH_PRIMARY(3, *fb); break;
-        case 5: RT_LAUNCH_PRIMARY(5, *fb); break;
-        default: RT_LAUNCH_PRIMARY(7, *fb); break;
+        case 0: RT_LAUNCH_PRIMARY_I(0, none, false); break;
+        case 1: RT_LAUNCH_PRIMARY_I(1, *fb, false); break;
+        default: RT_LAUNCH_PRIMARY_I(3, *fb, false); break;
     }
-#undef RT_LAUNCH_PRIMARY
+    switch (flags) {
+        case 0: break;
+        case 1: RT_LAUNCH_SURFACE(1, false); break;
+        case 3: RT_LAUNCH_SURFACE(3, false); break;
+        case 5: RT_LAUNCH_SURFACE(5, false); break;
+        default: RT_LAUNCH_SURFACE(7, false); break;
+    }
+#undef RT_LAUNCH_SURFACE
 #undef RT_LAUNCH_PRIMARY_I
     return hipGetLastError();
 }
