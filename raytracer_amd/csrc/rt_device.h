@@ -14,9 +14,6 @@
 #ifndef RT_RAYS_MIN_WAVES
 #define RT_RAYS_MIN_WAVES 4        // waves per SIMD the persistent kernel is compiled for (caps VGPRs at 128)
 #endif
-#ifndef RT_INST_PRIMARY_WAVES
-#define RT_INST_PRIMARY_WAVES 3    // closest-hit walks of two-level scenes carry two rays: 170 VGPRs pay there (measured)
-#endif
 #define RT_QUEUE_PARTS 8u          // work-queue heads per launch: one per XCD
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
 #define RT_REFILL_MIN 40           // finished lanes that must pile up before a wave swaps rays (default)

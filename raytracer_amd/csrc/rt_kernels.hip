@@ -14,9 +14,10 @@
 // ([entry][lane], conflict-free), with a private overflow for pathological depth.  The walk is
 // "while-while": lanes step through internal nodes until every lane of the wave holds a leaf (or is done),
 // then all leaf tests run together - FP64 leaf code is 10-40x a box test, so it must not run lane by lane.
-// The frame pipeline for max_scatters = 0 is three launches: k_primary (closest hit, surface record per
-// pixel), k_shadow (one wave per (tile, light): all lanes aim at the same light), k_resolve (sum the light
-// terms of the lights that reach each point in light order, ambient, albedo, gamma).
+// The frame pipeline for max_scatters = 0 is four launches: k_rays<0> (closest hit: the winning record per pixel),
+// k_surface (dense: the full surface record of each hit), k_rays<1> (shadow rays, one wave per (tile, light): all
+// lanes aim at the same light; a verdict per ray), k_resolve (dense: the terms of the lights that reach each point in
+// light order, ambient, albedo, gamma).  The ray kernels only walk: what can run densely does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -739,7 +740,7 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
 template <int MODE, bool COUNT, int RECORD, bool INST = false>
-__global__ void __launch_bounds__(64, (INST && MODE == 0) ? RT_INST_PRIMARY_WAVES : RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
+__global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
