@@ -51,7 +51,7 @@ struct PixelMap {
     int tile, tiles_x, n_tiles, rank, n_ranks;
 };
 
-// Per-frame working set of the three-launch pipeline (all planes have n entries, indexed by output slot).
+// Per-frame working set of the frame pipeline (closest hit, surface records, shadow verdicts, resolve) (all planes have n entries, indexed by output slot).
 struct FrameBufs {
     double *px, *py, *pz;          // hit point
     double *nx, *ny, *nz;          // unit normal, re-normalised as RayTracer::shade does
