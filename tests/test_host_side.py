@@ -275,6 +275,31 @@ def test_bvh_walk_with_loose_degenerate_and_tied_primitives(oracle):
     assert np.array_equal(got.astype(bool), want)
 
 
+def test_scene_spanning_primitives_stay_beside_the_tree(oracle):
+    """A primitive that spans a quarter of the scene or more (a ground plane) is kept out of the hierarchy and tested
+    against every ray; at most 8 of them, and only in scenes of more than 16 primitives.  The walk still equals brute
+    force."""
+    prims = S.mixed_field(n_side=24, seed=9)                      # 24 x 24 cells and a ground plane
+    lights = S.mixed_field_lights(half_extent=12.0, height=6.0, intensity=40.0)
+    sc = capi.Scene.create(prims, lights)
+    info = sc.info()
+    nodes, slots, n_slots, n_loose, radius = sc.bvh()
+    ground = int(np.flatnonzero(prims["kind"] == S.PLANE)[-1])
+    assert info.n_loose == 1 and slots[n_slots:].tolist() == [ground]
+    check_bvh(sc, oracle)
+    cam = oracle.camera(**{k: v for k, v in zip(("pos", "direction"), ([0.0, -17.0, 8.5], [0.0, 0.8, -0.45]))}, res=(160, 90))
+    osc = oracle.scene(prims, lights)
+    ids, rgb, _, _ = oracle.bvh_render(osc, oracle_bvh(oracle, sc), cam)
+    want_ids, _ = oracle.trace_primary(osc, cam)
+    assert (want_ids == ground).mean() > 0.05
+    assert np.array_equal(ids, want_ids) and np.array_equal(rgb, oracle.render(osc, cam, max_scatters=0)[0])
+    # nine spanning planes are more than the rule takes out: they all stay in the tree
+    many = np.concatenate([prims] + [prims[ground:ground + 1]] * 8)
+    assert capi.Scene.create(S.sort_reference_order(many), lights).info().n_loose == 0
+    # a small scene keeps everything in the tree
+    assert capi.Scene.create(np.concatenate([prims[:10], prims[ground:ground + 1]]), lights).info().n_loose == 0
+
+
 @pytest.mark.parametrize("kind", [S.CUBE, S.PLANE, S.CYLINDER, S.SPHERE])
 def test_library_aabbs_of_constructed_primitives(kind):
     """compute_aabb of primitives built through the reference's constructors, bit for bit: this pins the library's
