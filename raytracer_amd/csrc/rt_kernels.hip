@@ -325,7 +325,12 @@ struct Stack {
     DEV uint32_t pop(float limit) {
         while (sp) {
             --sp;
-            const uint2 e = (sp < RT_STACK_LDS) ? g_lds_stack[sp * 64u + lane] : deep[sp - RT_STACK_LDS];
+            // an LDS read in any case (of a clamped slot), replaced from the private part when the entry lives there:
+            // left to itself the compiler picks between the two addresses and reads through one flat load, which is
+            // much slower than ds_read
+            uint2 e = g_lds_stack[(sp < RT_STACK_LDS ? sp : RT_STACK_LDS - 1u) * 64u + lane];
+            asm volatile("" : "+v"(e.x), "+v"(e.y));          // keeps the read where it is, as a ds_read
+            if (sp >= RT_STACK_LDS) e = deep[sp - RT_STACK_LDS];
             if (__uint_as_float(e.y) <= limit) return e.x;
         }
         return REF_NONE;
