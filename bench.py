@@ -27,7 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+FP32_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak
 NODE_BYTES, PRIM_BYTES = 32, 64
+# algorithmic flops: a slab test (6 sub, 6 mul, 12 min/max, 6 compares), a primitive test by kind (cube / cylinder: two
+# 3x3 matrix-vector products and slabs or a quadratic; ellipsoid; plane / triangle)
+NODE_FLOPS = 30
+PRIM_FLOPS = {0: 120, 1: 75, 2: 120, 3: 45, 4: 75}
 
 
 def cpu_model():
@@ -63,8 +68,26 @@ def cpu_baseline(scene, prims, lights, camd, budget_s, threads):
     dt = time.perf_counter() - t0
     n_px = ((W + step - 1) // step) * ((H + step - 1) // step)
     rays = n_px + hits * len(lights)
+    # the same walk on one thread, and the reference's own algorithm (every primitive against every ray, strict '<') on
+    # one thread: a few seconds each, on coarser samples of the same frame
+    step1 = max(step, int(np.ceil(np.sqrt(W * H * per_px * threads / 3.0))))
+    t0 = time.perf_counter()
+    _, _, _, hits1 = O.bvh_render(osc, bvh, cam, step=step1, threads=1)
+    dt1 = time.perf_counter() - t0
+    rays1 = ((W + step1 - 1) // step1) * ((H + step1 - 1) // step1) + hits1 * len(lights)
+    n_brute = max(4, int(3.0 / (150e-9 * max(len(prims), 1))))
+    rng = np.random.default_rng(1)
+    pix = np.stack([rng.integers(0, W, n_brute) + 0.5, rng.integers(0, H, n_brute) + 0.5], axis=1)
+    brute_rays = O.pixel_rays(cam, pix)
+    t0 = time.perf_counter()
+    O.trace_rays(osc, brute_rays, threads=1)
+    dtb = time.perf_counter() - t0
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "single_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "sample": "every %dth pixel, %d rays, %.1f s" % (step1, rays1, dt1)},
+        "brute_force_single_thread": {"value": n_brute / dtb / 1e6, "unit": "Mrays/s",
+                                      "sample": "%d primary rays against all %d primitives (the reference's one_pass_intersection), %.1f s"
+                                                % (n_brute, len(prims), dtb)},
         "sample": "every %dth pixel in x and y of the same frame (%d primary + %d shadow rays, %.1f s), "
                   "FP64 C restatement through the same flattened BVH, OpenMP x%d, CPU: %s"
                   % (step, n_px, hits * len(lights), dt, threads, cpu_model()),
@@ -196,6 +219,9 @@ def main():
     # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights and per bounce level
     kname, k_ms, k_bytes = ("k_rays<1,false,0,true>" if args.instanced else "k_rays<1,false,0,false>") + " (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
         bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
+    by_kind = [int(v) for v in info.n_by_kind]
+    prim_flops = sum(PRIM_FLOPS.get(k, 0) * n for k, n in enumerate(by_kind)) / max(sum(by_kind), 1)
+    k_flops = (NODE_FLOPS * c["nodes_shadow"] + prim_flops * c["prims_shadow"]) / max(tm["shadow_launches"] // args.steps, 1)
     stage_ms = {k: tm[k] / args.steps for k in ("primary_ms", "shadow_ms", "resolve_ms", "bounce_ms")}
     t = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -247,6 +273,11 @@ def main():
                 # ray fetches, and most of those fetches are served by L1 / L2, so it can exceed the HBM peak
                 "hbm_side_achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None,
                 "hbm_side_frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                # the secondary bound: algorithmic flops of the same launch against the FP32 vector peak
+                "fp32": {"achieved": k_flops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": k_flops / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": k_flops},
+                # what a frame must read and write at least once: every node and record, 3 bytes per pixel
+                "compulsory_bytes_per_frame": NODE_BYTES * int(info.n_nodes) + PRIM_BYTES * int(info.n_slots + info.n_loose) + 3 * W * H,
                 "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,
                 "algorithmic_bytes_per_launch": k_bytes,
                 "stage_ms_per_frame": stage_ms,
