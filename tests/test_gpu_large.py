@@ -85,6 +85,14 @@ def test_one_million_cells_4k(ctx, oracle):
     brute = oracle.trace_rays(oracle.scene(prims, lights), rays)
     assert np.array_equal(ids[py, px], brute["id"])
     assert np.array_equal(bits(tdist[py, px]), bits(brute["dist"]))
+    # shadow verdicts by brute force on 64 of them: shade() with every primitive tested for every shadow ray
+    sub = np.ascontiguousarray(rays[:64])
+    want_lin = oracle.shade_rays(oracle.scene(prims, lights), sub)
+    rt = torch.from_numpy(sub).cuda()
+    lin = torch.empty((len(sub), 3), dtype=torch.uint8, device="cuda")
+    ctx.shade_rays_dev(rt.data_ptr(), len(sub), lin.data_ptr())
+    ctx.synchronize()
+    assert want_lin.any() and np.abs(lin.cpu().numpy().astype(np.int16) - want_lin.astype(np.int16)).max() <= 1
     # the 8-GPU partition on this frame: 8 virtual ranks, 64-pixel tiles
     tiling = capi.Tiling(W, H, 64, 8)
     per = capi.tiles_per_rank(tiling) * 64 * 64 * 3
