@@ -592,8 +592,13 @@ int next_queue(rt_ctx* ctx, unsigned int** q) {
     return RT_OK;
 }
 
+// Persistent waves for a launch over n_tiles tiles of 64 rays: as many as stay resident, but no more than leave every
+// lane about eight rays to walk - a small launch (one rank's share of a tiled frame) otherwise spends most of its time
+// in the ramp and the tail of waves that carry three or four rays per lane.
 uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
-    return static_cast<uint32_t>(n_tiles < ctx->max_waves ? (n_tiles ? n_tiles : 1) : ctx->max_waves);
+    uint64_t want = n_tiles / 8u;
+    if (want < 256u) want = n_tiles < 256u ? (n_tiles ? n_tiles : 1u) : 256u;
+    return static_cast<uint32_t>(want < ctx->max_waves ? want : ctx->max_waves);
 }
 
 // Carve the frame working set out of the context's grow-only scratch (allocated on first use of a size).
