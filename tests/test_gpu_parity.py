@@ -639,3 +639,45 @@ def test_device_build_edge_sizes(ctx, oracle):
     assert np.array_equal(ids, want_ids) and np.array_equal(bits(dist), bits(want_dist))
     with pytest.raises(capi.RtError):
         capi.Scene.create(prims, lights, on_device=True).bvh()           # nothing on the host to hand out
+
+
+@pytest.mark.parametrize("seed", list(range(400, 412)))
+def test_random_scenes_against_brute_force(ctx, oracle, seed):
+    """A dozen more seeded scenes of all five kinds, some with duplicated, degenerate and scene-spanning primitives, both
+    host- and device-built hierarchies: ids and FP64 distances equal brute force bit for bit, colours within one level
+    for 0 and 2 bounces, arbitrary rays (unnormalised, axis-parallel, starting inside primitives) included."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 90))
+    prims, lights, camd = S.random_scene(n, seed, kinds=(S.CUBE, S.PLANE, S.CYLINDER, S.SPHERE, S.TRIANGLE), lights=int(rng.integers(1, 4)))
+    extra = []
+    if seed % 2 == 0:                                   # a copy of some primitive: equal distances, lowest id wins
+        extra.append(prims[int(rng.integers(0, n))].copy())
+    if seed % 3 == 0:                                   # a floor under everything
+        g = S.new_prims(1); g["kind"] = S.PLANE; g["q"][0, :12] = [-9, -9, -3.5, 9, -9, -3.5, 9, 9, -3.5, -9, 9, -3.5]
+        g["metallic"] = 0.5
+        extra.append(g[0])
+    if seed % 4 == 0:                                   # a zero scale: unbounded, tested against every ray
+        z = S.new_prims(1); z["kind"] = S.CYLINDER; z["q"][0, :9] = [0.3, -0.4, 0.2, 0.5, 0.1, -0.7, 0.6, 0.0, 0.9]
+        extra.append(z[0])
+    if extra:
+        prims = S.sort_reference_order(np.concatenate([prims, np.array(extra, dtype=prims.dtype)]))
+    camd = dict(camd, res=(112, 63))
+    cam = capi.make_camera(**camd)
+    osc = oracle.scene(prims, lights)
+    want_ids, want_dist = oracle.trace_primary(osc, ocamera(cam))
+    want = {ms: oracle.render(osc, ocamera(cam), max_scatters=ms)[0] for ms in (0, 2)}
+    o = rng.uniform(-4, 4, size=(3000, 3))
+    d = rng.normal(size=(3000, 3)) * rng.uniform(0.01, 30, size=(3000, 1))
+    d[:30, 0] = 0.0
+    d[30:60, 1:] = 0.0
+    o[60:200] = prims["q"][rng.integers(0, len(prims), 140), :3] + rng.normal(size=(140, 3)) * 0.05      # from inside / on things
+    rays = np.concatenate([o, d], axis=1)
+    a = oracle.trace_rays(osc, rays)
+    for on_device in (False, True):
+        ctx.upload(capi.Scene.create(prims, lights, on_device=on_device, max_leaf=1 + seed % 3))
+        ids, dist = ctx.trace_primary(cam)
+        assert np.array_equal(ids, want_ids) and np.array_equal(bits(dist), bits(want_dist)), on_device
+        for ms in (0, 2):
+            assert_rgb_close(ctx.render(cam, max_scatters=ms), want[ms], max_frac=2e-3)
+        rid, rdist = ctx.trace_rays(rays)
+        assert np.array_equal(rid, a["id"]) and np.array_equal(bits(rdist), bits(a["dist"])), on_device
