@@ -10,8 +10,10 @@
  * hit records, 8-bit colours) against the real reference engine compiled from its own sources
  * (oracle/_ref, built by oracle/Makefile) by tests/test_oracle_vs_ref.py in the development
  * container, and against golden fixtures generated from that engine (tests/golden/) everywhere.
- * The triangle primitive is the one exception: the reference has no triangle, so it is pinned only
- * indirectly (two triangles of a parallelogram against the reference Plane).
+ * Two exceptions, both extensions the reference does not have: the triangle primitive is pinned only
+ * indirectly (two triangles of a parallelogram against the reference Plane), and two-level scenes
+ * (rto_instance) are parity unpinned - tied to the pinned plain path by construction tests only (an
+ * identity instance reproduces the plain scene bit for bit, tests/test_instancing.py).
  *
  * Arithmetic follows the reference operation by operation so that results agree to the last bit
  * when compiled without FMA contraction (-ffp-contract=off, no -ffast-math).
