@@ -68,6 +68,11 @@ typedef struct rt_rect { int32_t x0, y0, w, h; } rt_rect;
  * count > 0: leaf over primitive slots [first, first + count). */
 typedef struct rt_node32 { float lo[3]; uint32_t first; float hi[3]; uint32_t count; } rt_node32;
 
+/* Wide node, 128 bytes: up to four subtrees of the binary tree side by side (boxes by component: lo[axis][child],
+ * hi[axis][child]).  ref[child]: bits 31..28 = primitive count of a leaf over slots [ref & 0x0FFFFFFF, +count), or 0 for
+ * an inner node whose wide node has that index; 0xFFFFFFFF = no child.  Wide node 0 holds the children of the root. */
+typedef struct rt_node4 { float lo[3][4]; float hi[3][4]; uint32_t ref[4]; uint32_t pad[4]; } rt_node4;
+
 typedef struct rt_build_opts {
     uint32_t max_leaf;        /* primitives per leaf, 1..8 (0 = default 1) */
     uint32_t sah_bins;        /* 4..32 (0 = default 32) */
@@ -159,6 +164,11 @@ int rt_scene_get_prims(const rt_scene* scene, const rt_prim_desc** prims, uint64
 int rt_scene_get_lights(const rt_scene* scene, const rt_light** lights, uint32_t* n);
 int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n_nodes,
                      const uint32_t** slot_prim, uint64_t* n_slots);
+/* The hierarchy as the kernels walk it for host-built, non-instanced scenes: the binary tree collapsed into wide nodes
+ * (one 128-byte fetch and four box tests per step instead of two steps; the same boxes, the same leaves).  n = 0 when
+ * the scene is walked through the binary nodes (device-built, instanced, a single leaf, or a tree so lopsided that the
+ * wide walk could need more than the traversal stack holds). */
+int rt_scene_get_wide_bvh(const rt_scene* scene, const rt_node4** nodes4, uint32_t* n_nodes4);
 /* Camera by id as read_all_cameras builds it (raytracer.cpp:29-68); RT_ERR_NOT_FOUND if absent.
  * index >= 0 with id == NULL enumerates cameras in file order; id_out (>= 32 bytes) may be NULL. */
 int rt_scene_camera(const rt_scene* scene, const char* id, int32_t index, rt_camera* out, char* id_out);

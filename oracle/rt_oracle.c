@@ -840,7 +840,43 @@ static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int 
     int64_t vn = 0;
     int closed = 0;
 
-    if (B->n_nodes > 0) {
+    if (B->nodes4 && B->n_nodes4 > 0 && B->n_nodes > 0) {
+        /* the product's wide walk, restated: node records fetched = the root once, then four per wide node visited */
+        const uint32_t NONE = 0xFFFFFFFFu;
+        struct { uint32_t ref; float t; } wstack[96];
+        int wsp = 0;
+        uint32_t cur = NONE;
+        const rto_node32 root = B->nodes[0]; vn += 1;
+        if (box_entry(&root, &br, w.limit_f) != __builtin_inff()) cur = 0u;
+        for (;;) {
+            if (cur == NONE) {
+                while (wsp > 0 && cur == NONE) { --wsp; if (wstack[wsp].t <= w.limit_f) cur = wstack[wsp].ref; }
+                if (cur == NONE) break;
+            }
+            if (cur >> 28) {
+                const uint32_t first = cur & 0x0FFFFFFFu, count = cur >> 28;
+                for (uint32_t s = 0; s < count && !closed; ++s) closed = walk_slot(&w, first + s);
+                if (closed) break;
+                cur = NONE;
+                continue;
+            }
+            const rto_node4* n4 = &B->nodes4[cur]; vn += 4;
+            float t[4]; uint32_t r[4];
+            for (int k = 0; k < 4; ++k) {
+                rto_node32 nd;
+                for (int a = 0; a < 3; ++a) { nd.lo[a] = n4->lo[a][k]; nd.hi[a] = n4->hi[a][k]; }
+                t[k] = box_entry(&nd, &br, w.limit_f);
+                r[k] = n4->ref[k];
+            }
+            if (r[2] == NONE) t[2] = __builtin_inff();
+            if (r[3] == NONE) t[3] = __builtin_inff();
+#define RTO_EXCHANGE(i, j) if (t[j] < t[i]) { const float tt = t[i]; t[i] = t[j]; t[j] = tt; const uint32_t rr = r[i]; r[i] = r[j]; r[j] = rr; }
+            RTO_EXCHANGE(0, 1) RTO_EXCHANGE(2, 3) RTO_EXCHANGE(0, 2) RTO_EXCHANGE(1, 3) RTO_EXCHANGE(1, 2)
+#undef RTO_EXCHANGE
+            for (int k = 3; k >= 1; --k) if (t[k] != __builtin_inff()) { wstack[wsp].ref = r[k]; wstack[wsp].t = t[k]; ++wsp; }
+            cur = (t[0] != __builtin_inff()) ? r[0] : NONE;
+        }
+    } else if (B->n_nodes > 0) {
         const rto_node32 root = B->nodes[0]; vn += 1;
         int have = (box_entry(&root, &br, w.limit_f) != __builtin_inff());
         uint32_t first = root.first, count = root.count;

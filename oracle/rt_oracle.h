@@ -119,10 +119,18 @@ void rto_gamma_lut(uint8_t lut[256]);
 /* The product's flattened BVH, as rt_scene_get_bvh / rt_scene_get_info hand it out: slot_prim maps
  * primitive slots to ids, the first n_slots in BVH leaf order followed by n_loose unbounded primitives
  * that every ray tests; radius scales the FP32 box padding (2^-18 * max(|origin|, radius)). */
+/* The product's wide node (rt_node4): up to four subtrees of the binary tree side by side, boxes by component
+ * (lo[axis][child]); ref[child] = count << 28 | first slot for a leaf, the index of another wide node for an inner
+ * child, all ones for an empty place.  Wide node 0 holds the children of the binary root. */
+typedef struct rto_node4 { float lo[3][4]; float hi[3][4]; uint32_t ref[4]; uint32_t pad[4]; } rto_node4;
+
 typedef struct rto_bvh {
     const rto_node32* nodes; int64_t n_nodes;
     const uint32_t* slot_prim; int64_t n_slots; int64_t n_loose;
     float radius;
+    /* when set, the walk goes through the wide nodes exactly as the product's does (root box from nodes[0], then four
+     * boxes per step, entered children ordered by a five-exchange network, nearest first) */
+    const rto_node4* nodes4; int64_t n_nodes4;
 } rto_bvh;
 
 /* Closest hit through the BVH with FP32 padded boxes and FP64 leaf tests; same result as rto_closest_hit by

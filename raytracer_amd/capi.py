@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "librt_hip.so")
 
 NODE_DT = np.dtype([("lo", "<f4", (3,)), ("first", "<u4"), ("hi", "<f4", (3,)), ("count", "<u4")])
+NODE4_DT = np.dtype([("lo", "<f4", (3, 4)), ("hi", "<f4", (3, 4)), ("ref", "<u4", (4,)), ("pad", "<u4", (4,))])   # rt_node4
 
 RT_OK = 0
 STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_IO", -3: "RT_ERR_NOT_FOUND", -4: "RT_ERR_NO_DEVICE",
@@ -87,6 +88,7 @@ SYMBOLS = [
     ("rt_scene_get_prims", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U64)]),
     ("rt_scene_get_lights", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U32)]),
     ("rt_scene_get_bvh", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U32), C.POINTER(_VP), C.POINTER(_U64)]),
+    ("rt_scene_get_wide_bvh", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U32)]),
     ("rt_scene_camera", C.c_int, [_VP, C.c_char_p, _I32, C.POINTER(Camera), C.c_char_p]),
     ("rt_prim_aabb", C.c_int, [_VP, _DP]),
     ("rt_camera_look", C.c_int, [_DP, _DP, _DP, C.POINTER(Camera)]),
@@ -318,6 +320,15 @@ class Scene:
         if total:
             slots = np.frombuffer((C.c_char * (total * 4)).from_address(ps.value), dtype=np.uint32).copy()
         return nodes, slots, int(ns.value), int(info.n_loose), float(np.nextafter(np.float32(info.radius), np.float32(np.inf)))
+
+    def wide_bvh(self):
+        """The wide nodes the kernels walk (NODE4_DT), empty when the scene is walked through the binary tree."""
+        p, n = C.c_void_p(), C.c_uint32()
+        _check(lib().rt_scene_get_wide_bvh(self.h, C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, NODE4_DT)
+        buf = (C.c_char * (n.value * NODE4_DT.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=NODE4_DT).copy()
 
     def camera(self, camera_id=None, index=-1):
         cam = Camera()

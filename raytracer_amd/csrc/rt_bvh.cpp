@@ -150,6 +150,61 @@ struct Builder {
 
 } // namespace
 
+// A wide node takes the two children of a binary inner node and, twice, replaces the inner child with the largest box by
+// that child's own two children: up to four subtrees whose boxes a ray tests in one step.  Children of wide node w that
+// are inner nodes become wide nodes of their own; leaves keep their slot range.  The walk pushes up to three postponed
+// subtrees per step, so the stack it can need is computed here (children are visited nearest first, the others wait).
+uint32_t rt_collapse_wide(const std::vector<rt_node32>& bn, std::vector<rt_node4>& out) {
+    out.clear();
+    if (bn.empty() || bn[0].count != 0) return 0;
+    struct Todo { uint32_t bin, self; };
+    std::vector<Todo> todo;
+    out.push_back(rt_node4{}); todo.push_back({0u, 0u});
+    while (!todo.empty()) {
+        const Todo td = todo.back(); todo.pop_back();
+        uint32_t ch[4]; int nch = 2;
+        ch[0] = bn[td.bin].first; ch[1] = ch[0] + 1;
+        while (nch < 4) {
+            int best = -1; double best_area = -1.0;
+            for (int k = 0; k < nch; ++k) {
+                const rt_node32& nd = bn[ch[k]];
+                if (nd.count) continue;
+                const double ex = double(nd.hi[0]) - nd.lo[0], ey = double(nd.hi[1]) - nd.lo[1], ez = double(nd.hi[2]) - nd.lo[2];
+                const double a = ex*ey + ey*ez + ez*ex;
+                if (a > best_area) { best_area = a; best = k; }
+            }
+            if (best < 0) break;
+            const uint32_t f = bn[ch[best]].first;
+            ch[best] = f; ch[nch++] = f + 1;
+        }
+        rt_node4 w; std::memset(&w, 0, sizeof(w));
+        for (int k = 0; k < 4; ++k) {
+            if (k < nch) {
+                const rt_node32& nd = bn[ch[k]];
+                for (int a = 0; a < 3; ++a) { w.lo[a][k] = nd.lo[a]; w.hi[a][k] = nd.hi[a]; }
+                if (nd.count) w.ref[k] = (nd.count << 28) | nd.first;
+                else { w.ref[k] = static_cast<uint32_t>(out.size()); out.push_back(rt_node4{}); todo.push_back({ch[k], w.ref[k]}); }
+            } else {
+                for (int a = 0; a < 3; ++a) { w.lo[a][k] = INFINITY; w.hi[a][k] = -INFINITY; }
+                w.ref[k] = 0xFFFFFFFFu;
+            }
+        }
+        out[td.self] = w;
+    }
+    // stack need: entering child c of a node leaves the node's other children on the stack
+    std::vector<uint32_t> need(out.size(), 0);
+    for (size_t i = out.size(); i-- > 0;) {                 // children have larger indices than their parent
+        uint32_t n_children = 0, deepest = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (out[i].ref[k] == 0xFFFFFFFFu) continue;
+            ++n_children;
+            if ((out[i].ref[k] >> 28) == 0) deepest = std::max(deepest, need[out[i].ref[k]]);
+        }
+        need[i] = (n_children ? n_children - 1 : 0) + deepest;
+    }
+    return need[0];
+}
+
 void rt_build_bvh(const std::vector<rt_box64>& boxes, uint32_t max_leaf, uint32_t bins, rt_bvh_result& out) {
     out.nodes.clear(); out.order.clear(); out.depth = 0;
     const uint32_t n = static_cast<uint32_t>(boxes.size());

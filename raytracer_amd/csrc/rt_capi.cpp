@@ -49,6 +49,7 @@ struct rt_ctx {
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
     uint8_t* d_texels = nullptr; rt_tex_rec* d_tex_table = nullptr;
+    rt_node4* d_nodes4 = nullptr;          // wide nodes of host-built scenes
     rt_inst_rec* d_inst = nullptr;         // two-level scenes
     uint32_t* d_slot_prim = nullptr;       // slot -> primitive id, as uploaded or as the device build ordered it
     uint32_t n_nodes_dev = 0; uint64_t n_slots_dev = 0;
@@ -87,6 +88,8 @@ struct rt_ctx {
         if (d_tex_table) (void)hipFree(d_tex_table);
         if (d_slot_prim) (void)hipFree(d_slot_prim);
         if (d_inst) (void)hipFree(d_inst);
+        if (d_nodes4) (void)hipFree(d_nodes4);
+        d_nodes4 = nullptr;
         d_slot_prim = nullptr; d_inst = nullptr;
         d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr; d_texels = nullptr; d_tex_table = nullptr;
         have_scene = false;
@@ -300,6 +303,13 @@ int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n
     if (scene->device_build) return fail(RT_ERR_NOT_FOUND, "this scene's hierarchy is built on the device: see rt_ctx_download_bvh");
     *nodes = scene->nodes.data(); *n_nodes = static_cast<uint32_t>(scene->nodes.size());
     *slot_prim = scene->slot_prim.data(); *n_slots = scene->n_slots;
+    return RT_OK;
+}
+
+int rt_scene_get_wide_bvh(const rt_scene* scene, const rt_node4** nodes4, uint32_t* n_nodes4) {
+    if (!scene) return fail(RT_ERR_INVALID, "null scene");
+    if (nodes4) *nodes4 = scene->nodes4.empty() ? nullptr : scene->nodes4.data();
+    if (n_nodes4) *n_nodes4 = static_cast<uint32_t>(scene->nodes4.size());
     return RT_OK;
 }
 
@@ -558,6 +568,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (rc == RT_OK) rc = upload(scene->texels, &ctx->d_texels);
     if (rc == RT_OK) rc = upload(scene->tex_table, &ctx->d_tex_table);
     if (rc == RT_OK) rc = upload(scene->inst_recs, &ctx->d_inst);
+    if (rc == RT_OK) rc = upload(scene->nodes4, &ctx->d_nodes4);
     if (rc != RT_OK) { ctx->free_scene(); return rc; }
     DevScene& d = ctx->sc;
     d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
@@ -569,6 +580,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.n_prims = static_cast<uint32_t>(scene->prims.size());
     d.texels = ctx->d_texels; d.tex_table = ctx->d_tex_table;
     d.n_textures = static_cast<uint32_t>(scene->tex_table.size());
+    d.nodes4 = reinterpret_cast<const float4*>(ctx->d_nodes4);
+    for (int k = 0; k < 3; ++k) { d.root_lo[k] = 0.0f; d.root_hi[k] = 0.0f; }
+    if (ctx->d_nodes4) for (int k = 0; k < 3; ++k) { d.root_lo[k] = scene->nodes[0].lo[k]; d.root_hi[k] = scene->nodes[0].hi[k]; }
     d.inst = ctx->d_inst; d.n_inst = static_cast<uint32_t>(scene->inst_recs.size());
     // round the radius up: the padding must not shrink through the conversion
     d.radius = std::nextafterf(static_cast<float>(scene->info.radius), INFINITY);

@@ -51,6 +51,7 @@ static_assert(sizeof(rt_prim_rec) == 160, "record layout");
 static_assert(sizeof(rt_mat_rec) == 32, "material layout");
 static_assert(sizeof(rt_inst_rec) == 128, "instance layout");
 static_assert(sizeof(rt_node32) == 32, "node layout");
+static_assert(sizeof(rt_node4) == 128, "wide node layout");
 static_assert(sizeof(rt_prim_desc) == 160, "description layout");
 #endif
 

@@ -308,7 +308,8 @@ DEV bool ref_internal(uint32_t r) { return (r >> 28) == 0u; }
 
 // Per-lane stack: entries 0..RT_STACK_LDS-1 in LDS ([entry][lane]), deeper ones in a private array that lives
 // outside this struct (a dynamically indexed member would drag every field of the walker into scratch memory).
-template <bool INST> struct DeepStack { uint2 e[(INST ? RT_STACK_DEPTH_INST : RT_STACK_DEPTH) - RT_STACK_LDS]; };
+// BIG: two-level scenes (both trees and the marker between them) and the wide walk (up to three postponed subtrees per step)
+template <bool BIG> struct DeepStack { uint2 e[(BIG ? RT_STACK_DEPTH_INST : RT_STACK_DEPTH) - RT_STACK_LDS]; };
 // The LDS part is one file-scope array, indexed directly, so that the compiler emits ds_read / ds_write (a pointer
 // kept in a struct degrades to flat addressing).  Every ray kernel runs one wave per workgroup.
 __shared__ uint2 g_lds_stack[RT_STACK_LDS * 64];
@@ -372,7 +373,8 @@ DEV void hit_out_of_instance(const rt_inst_rec* in, HitD& h) {
 // beyond light_dist - 1e-4 are irrelevant; once one hit inside the interval is known only hits at
 // <= 1e-4 can still change the verdict, so the search limit collapses to 1e-4; any such hit ends it.
 // vn counts node records fetched (1 for the root, 2 per internal node visited), vp primitive records.
-template <int MODE, bool COUNT, bool INST = false>
+// WIDE: the scene carries wide nodes (four subtrees per node) and the walk goes through them.
+template <int MODE, bool COUNT, bool INST = false, bool WIDE = false>
 struct Walker {
     RayD r;                             // in the frame being walked: the world, or the current instance's
     RayD rw;                            // INST: the ray in the world
@@ -417,7 +419,12 @@ struct Walker {
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
-        if (sc.n_nodes) {
+        if (WIDE) {
+            // the root's box travels with the kernel arguments; wide node 0 holds the root's children
+            if (COUNT) vn += 1;
+            if (box_entry(make_float4(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2], 0.0f), make_float4(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2], 0.0f),
+                          br, limit_f) != __builtin_inff()) cur = 0u;
+        } else if (sc.n_nodes) {
             const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
             const float4 lo = nodes[0], hi = nodes[1];
             if (COUNT) vn += 1;
@@ -429,6 +436,31 @@ struct Walker {
 
     // One internal node: fetch both children (64 contiguous bytes), test, descend into the nearer, postpone the other.
     DEV void step_internal(const DevScene& sc) {
+        if (WIDE) {
+            // One wide node: 128 contiguous bytes, four boxes.  The children that the ray enters are put in order of their
+            // entry distance (a five-exchange sorting network); the walk goes on in the nearest, the others wait on the
+            // stack, farthest pushed first.  An empty place is told by its reference (the slab test orders a box's
+            // planes itself, so an inverted box does not read as a miss).
+            const float4* n4 = sc.nodes4 + 8u * static_cast<size_t>(cur);
+            const float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5], rf = n4[6];
+            if (COUNT) vn += 4;
+            float t0 = box_entry(make_float4(lox.x, loy.x, loz.x, 0.0f), make_float4(hix.x, hiy.x, hiz.x, 0.0f), br, limit_f);
+            float t1 = box_entry(make_float4(lox.y, loy.y, loz.y, 0.0f), make_float4(hix.y, hiy.y, hiz.y, 0.0f), br, limit_f);
+            float t2 = box_entry(make_float4(lox.z, loy.z, loz.z, 0.0f), make_float4(hix.z, hiy.z, hiz.z, 0.0f), br, limit_f);
+            float t3 = box_entry(make_float4(lox.w, loy.w, loz.w, 0.0f), make_float4(hix.w, hiy.w, hiz.w, 0.0f), br, limit_f);
+            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+            t2 = (r2 == REF_NONE) ? __builtin_inff() : t2;
+            t3 = (r3 == REF_NONE) ? __builtin_inff() : t3;
+#define RT_EXCHANGE(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; \
+                                      const uint32_t rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
+            RT_EXCHANGE(t0, r0, t1, r1) RT_EXCHANGE(t2, r2, t3, r3) RT_EXCHANGE(t0, r0, t2, r2) RT_EXCHANGE(t1, r1, t3, r3) RT_EXCHANGE(t1, r1, t2, r2)
+#undef RT_EXCHANGE
+            if (t3 != __builtin_inff()) st.push(r3, t3);
+            if (t2 != __builtin_inff()) st.push(r2, t2);
+            if (t1 != __builtin_inff()) st.push(r1, t1);
+            cur = (t0 != __builtin_inff()) ? r0 : st.pop(limit_f);
+            return;
+        }
         const float4* pair = reinterpret_cast<const float4*>(sc.nodes) + 4u * static_cast<size_t>(cur);
         const float4 llo = pair[0], lhi = pair[1], rlo = pair[2], rhi = pair[3];
         if (COUNT) vn += 2;
@@ -480,11 +512,11 @@ struct Walker {
 };
 
 // A whole walk in one go (arbitrary-ray and bounce kernels).
-template <int MODE, bool COUNT, bool INST = false>
+template <int MODE, bool COUNT, bool INST = false, bool WIDE = false>
 DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double light_dist,
                   Best& best, uint32_t& vn, uint32_t& vp) {
-    Walker<MODE, COUNT, INST> w; w.vn = 0; w.vp = 0;
-    DeepStack<INST> deep;
+    Walker<MODE, COUNT, INST, WIDE> w; w.vn = 0; w.vp = 0;
+    DeepStack<INST || WIDE> deep;
     w.start(sc, r, lds_stack, deep.e, light_dist);
     while (!w.done()) {
         // inner nodes: the wave stays here until every lane holds a leaf or has run out of nodes
@@ -570,7 +602,7 @@ DEV double light_value(const rt_light& L, const rt_mat_rec& m, double px, double
 }
 
 // One light's term of RayTracer::shade (raytracer.cpp:210-260) in one go; 0 when the light is blocked.
-template <bool COUNT, bool INST = false>
+template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
                       double nx, double ny, double nz, double view_ox, double view_oy, double view_oz,
                       uint2* lds_stack, ShadeCounters& ctr) {
@@ -578,7 +610,7 @@ DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m
     const double light_dist = shadow_ray(L, px, py, pz, nx, ny, nz, sr);
     Best b;
     ++ctr.shadow_rays;
-    if (traverse<1, COUNT, INST>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
+    if (traverse<1, COUNT, INST, WIDE>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
     return light_value(L, m, px, py, pz, nx, ny, nz, sr.dx, sr.dy, sr.dz, view_ox, view_oy, view_oz);
 }
 
@@ -613,7 +645,7 @@ DEV uint32_t finish_shade(const rt_mat_rec& m, uint32_t albedo, double lighting)
 }
 
 // RayTracer::shade, raytracer.cpp:159-279, all lights in order inside one lane (megakernel path).
-template <bool COUNT, bool INST = false>
+template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec& m, uint32_t albedo, double view_ox, double view_oy,
                             double view_oz, uint2* lds_stack, ShadeCounters& ctr) {
     if (sc.n_lights == 0) return 0;
@@ -621,17 +653,17 @@ DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec&
     double lighting = 0.0;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const rt_light L = sc.lights[li];
-        lighting += light_term<COUNT, INST>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
+        lighting += light_term<COUNT, INST, WIDE>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
     }
     return finish_shade(m, albedo, lighting);
 }
 
 // h must carry u, v when the scene has textures.
-template <bool COUNT, bool INST = false>
+template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV uint32_t shade(const DevScene& sc, const HitD& h, int32_t id, double view_ox, double view_oy, double view_oz,
                    uint2* lds_stack, ShadeCounters& ctr) {
     const rt_mat_rec m = sc.mats[id];
-    return shade_material<COUNT, INST>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, lds_stack, ctr);
+    return shade_material<COUNT, INST, WIDE>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, lds_stack, ctr);
 }
 
 // Camera::pixelToRay, persp_camera.cpp:94-118 (effective sensor size precomputed on the host).
@@ -744,7 +776,7 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 //          k_bounce_resolve).
 // MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
 //          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
-template <int MODE, bool COUNT, int RECORD, bool INST = false>
+template <int MODE, bool COUNT, int RECORD, bool INST = false, bool WIDE = false>
 __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
@@ -752,8 +784,8 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     uint2* my_stack = nullptr;
     enum { IDLE = 0, TRAV = 1, DONE = 2 };
     uint32_t state = IDLE, out = 0, ridx = 0;
-    Walker<MODE, COUNT, INST> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
-    DeepStack<INST> deep;
+    Walker<MODE, COUNT, INST, WIDE> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
+    DeepStack<INST || WIDE> deep;
     uint32_t n_cast = 0, n_hit = 0;
     uint32_t q_next = 0, q_end = 0;          // wave-uniform: the unread part of the current chunk
     bool q_empty = false;
@@ -954,7 +986,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, Fra
 }
 
 // Arbitrary rays (origin, direction as 6 doubles): closest hit, optionally shaded (linear colour, no gamma).
-template <bool COUNT, bool SHADE, bool INST = false>
+template <bool COUNT, bool SHADE, bool INST = false, bool WIDE = false>
 __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __restrict__ rays, uint64_t n,
                                                    int32_t* __restrict__ ids, double* __restrict__ dist,
                                                    uint8_t* __restrict__ rgb, double* __restrict__ records, rt_counters* ctr) {
@@ -969,7 +1001,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
         r.dx = rays[i*6 + 3]; r.dy = rays[i*6 + 4]; r.dz = rays[i*6 + 5];
         r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
         Best b;
-        hit = traverse<0, COUNT, INST>(sc, r, my_stack, 0.0, b, vn, vp);
+        hit = traverse<0, COUNT, INST, WIDE>(sc, r, my_stack, 0.0, b, vn, vp);
         if (ids) ids[i] = b.id;
         if (dist) dist[i] = b.dist;
         if (records) {      // the Hit of the reference (utils.h:68-112): 16 doubles per ray
@@ -989,7 +1021,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
                 HitD h; h.u = 0.0; h.v = 0.0;
                 int32_t mat_id;
                 best_record<true, INST>(sc, b, r, h, mat_id);
-                c = shade<COUNT, INST>(sc, h, mat_id, r.ox, r.oy, r.oz, my_stack, sctr);
+                c = shade<COUNT, INST, WIDE>(sc, h, mat_id, r.ox, r.oy, r.oz, my_stack, sctr);
             }
             rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
         }
@@ -1026,7 +1058,7 @@ __global__ void __launch_bounds__(64) k_intersect_one(const rt_prim_rec* __restr
 
 // RayTracer::shade for caller-supplied hits: 10 doubles each (point, normal, primitive id, u, v, has-uv flag) and a
 // view origin (3 doubles) per hit; linear 8-bit colour out.
-template <bool INST>
+template <bool INST, bool WIDE>
 __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __restrict__ hits, const double* __restrict__ view,
                                                    uint64_t n, uint8_t* __restrict__ rgb, rt_counters* ctr) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
@@ -1042,13 +1074,13 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
             const rt_mat_rec m = sc.mats[static_cast<int32_t>(idf)];
             // a texture is only consulted when the Hit carries surface coordinates (mesh.cpp:23)
             const uint32_t alb = (hits[i*10 + 9] != 0.0) ? albedo_at(sc, m, h.u, h.v) : solid_albedo(m);
-            c = shade_material<false, INST>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            c = shade_material<false, INST, WIDE>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
         } else if (idf == -2.0) {
             // a hit that names no primitive: white, non-metallic, roughness 0.5 (raytracer.cpp:204-208, 250-254, 268-272)
             rt_mat_rec m;
             m.metallic = 0.0; m.roughness = 0.5; m.ior = 1.5; m.albedo[0] = 255; m.albedo[1] = 255; m.albedo[2] = 255;
             m.tex = -1;
-            c = shade_material<false, INST>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            c = shade_material<false, INST, WIDE>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
         }
         rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
     }
@@ -1184,11 +1216,13 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
     const dim3 grid(n_waves), block(64);
     const int variant = !fb ? 0 : (1 | (fb->ray ? 2 : 0));
     const int flags = !fb ? 0 : (variant | (fb->albedo ? 4 : 0));
-#define RT_LAUNCH_PRIMARY_I(R, FB, I)                                                                                                    \
+#define RT_LAUNCH_PRIMARY_IW(R, FB, I, W)                                                                                                \
     do {                                                                                                                                 \
-        if (counting) hipLaunchKernelGGL((k_rays<0, true, R, I>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min);  \
-        else          hipLaunchKernelGGL((k_rays<0, false, R, I>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
+        if (counting) hipLaunchKernelGGL((k_rays<0, true, R, I, W>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min);  \
+        else          hipLaunchKernelGGL((k_rays<0, false, R, I, W>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
     } while (0)
+#define RT_LAUNCH_PRIMARY_I(R, FB, I)                                                                                                    \
+    do { if (!(I) && sc->nodes4) RT_LAUNCH_PRIMARY_IW(R, FB, false, true); else RT_LAUNCH_PRIMARY_IW(R, FB, I, false); } while (0)
 #define RT_LAUNCH_SURFACE(F, I) hipLaunchKernelGGL((k_surface<F, I>), dim3((n_tiles + 3u) / 4u), dim3(256), 0, st, *sc, *cam, *pm, n_tiles, *fb)
     if (sc->inst) {                     // two-level scene (no textures there)
         switch (variant) {
@@ -1212,6 +1246,7 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
     }
 #undef RT_LAUNCH_SURFACE
 #undef RT_LAUNCH_PRIMARY_I
+#undef RT_LAUNCH_PRIMARY_IW
     return hipGetLastError();
 }
 
@@ -1222,6 +1257,11 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
     if (sc->inst) {
         if (counting) hipLaunchKernelGGL((k_rays<1, true, 0, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
         else          hipLaunchKernelGGL((k_rays<1, false, 0, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+        return hipGetLastError();
+    }
+    if (sc->nodes4) {
+        if (counting) hipLaunchKernelGGL((k_rays<1, true, 0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+        else          hipLaunchKernelGGL((k_rays<1, false, 0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
         return hipGetLastError();
     }
     if (counting) hipLaunchKernelGGL((k_rays<1, true, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
@@ -1240,23 +1280,20 @@ extern "C" hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, c
                                            int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr) {
     const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
     if (nb == 0) return hipSuccess;
-    if (sc->inst) {
-        if (shade_it) {
-            if (counting) hipLaunchKernelGGL((k_trace_rays<true, true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-            else          hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-        } else {
-            if (counting) hipLaunchKernelGGL((k_trace_rays<true, false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-            else          hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-        }
-        return hipGetLastError();
-    }
-    if (shade_it) {
-        if (counting) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-        else          hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-    } else {
-        if (counting) hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-        else          hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);
-    }
+#define RT_LAUNCH_TRACE(I, W)                                                                                                                      \
+    do {                                                                                                                                           \
+        if (shade_it) {                                                                                                                            \
+            if (counting) hipLaunchKernelGGL((k_trace_rays<true, true, I, W>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);  \
+            else          hipLaunchKernelGGL((k_trace_rays<false, true, I, W>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr); \
+        } else {                                                                                                                                   \
+            if (counting) hipLaunchKernelGGL((k_trace_rays<true, false, I, W>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr); \
+            else          hipLaunchKernelGGL((k_trace_rays<false, false, I, W>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);\
+        }                                                                                                                                          \
+    } while (0)
+    if (sc->inst) RT_LAUNCH_TRACE(true, false);
+    else if (sc->nodes4) RT_LAUNCH_TRACE(false, true);
+    else RT_LAUNCH_TRACE(false, false);
+#undef RT_LAUNCH_TRACE
     return hipGetLastError();
 }
 
@@ -1269,8 +1306,9 @@ extern "C" hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec*
 extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
                                            uint8_t* rgb, rt_counters* ctr) {
     const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
-    if (nb && sc->inst) hipLaunchKernelGGL(k_shade_hits<true>, dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
-    else if (nb)        hipLaunchKernelGGL(k_shade_hits<false>, dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    if (nb && sc->inst)        hipLaunchKernelGGL((k_shade_hits<true, false>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    else if (nb && sc->nodes4) hipLaunchKernelGGL((k_shade_hits<false, true>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    else if (nb)               hipLaunchKernelGGL((k_shade_hits<false, false>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
     return hipGetLastError();
 }
 

@@ -89,6 +89,7 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
     rt_bvh_result top;
     rt_build_bvh(inst_boxes, 1, bins, top);
     s->nodes = top.nodes;
+    s->nodes4.clear();
     s->recs.clear(); s->slot_prim.clear();
     uint32_t mesh_depth = 0;
     for (auto& kv : meshes) {
@@ -226,6 +227,8 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
         rt_build_bvh(boxes, max_leaf, bins, bvh);
     }
     s->nodes.swap(bvh.nodes);
+    s->nodes4.clear();
+    if (!s->device_build && rt_collapse_wide(s->nodes, s->nodes4) >= RT_STACK_DEPTH_INST - 1) s->nodes4.clear();   // too lopsided for the wide walk's stack
     s->n_slots = bounded_recs.size();
     s->n_loose = loose.size();
     s->recs.clear(); s->recs.reserve(s->n_slots + s->n_loose);

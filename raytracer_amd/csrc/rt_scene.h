@@ -19,6 +19,7 @@ struct rt_scene {
     std::vector<rt_mat_rec>   mats;                  // by id
     std::vector<rt_prim_rec>  recs;                  // BVH slot order, then the loose primitives
     std::vector<rt_node32>    nodes;                 // node 0 = root, node 1 unused, sibling pairs at even indices
+    std::vector<rt_node4>     nodes4;                // the same tree collapsed into wide nodes (empty: walk the binary one)
     std::vector<uint32_t>     slot_prim;             // slot -> id (bounded, BVH order; loose ones appended)
     uint64_t n_slots = 0, n_loose = 0;
     rt_scene_info info{};
@@ -50,6 +51,9 @@ void rt_gamma_table(uint8_t lut[256]);
 // rt_bvh.cpp
 struct rt_bvh_result { std::vector<rt_node32> nodes; std::vector<uint32_t> order; uint32_t depth = 0; };
 void rt_build_bvh(const std::vector<rt_box64>& boxes, uint32_t max_leaf, uint32_t bins, rt_bvh_result& out);
+// Collapse a binary tree into wide nodes; returns the stack entries a walk of the result can need (0 and an empty
+// result when the root is a leaf or there is no tree).
+uint32_t rt_collapse_wide(const std::vector<rt_node32>& nodes, std::vector<rt_node4>& out);
 
 // rt_json.cpp; tex_paths receives one entry per primitive ("" = no albedo_texture_ppm given)
 int rt_parse_scene_file(const char* path, std::vector<rt_prim_desc>& prims, std::vector<rt_light>& lights,

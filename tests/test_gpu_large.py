@@ -24,7 +24,7 @@ def ctx():
 
 def oracle_bvh(oracle, sc):
     nodes, slots, n_slots, n_loose, radius = sc.bvh()
-    return oracle.bvh(nodes, slots, n_slots, n_loose, radius)
+    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh())      # walked the way the kernels walk it
 
 
 def ocamera(cam):

@@ -157,12 +157,55 @@ def check_bvh(sc, oracle):
     return max_depth
 
 
+def check_wide(sc, may_be_dropped=False):
+    """The wide nodes are the binary tree with up to two inner children opened per node: every binary leaf appears
+    exactly once with its slot range and its box, every child box is one of the binary tree's, node 0 holds the root's
+    children, and a binary walk and a wide walk reach the same leaves."""
+    nodes, slots, n_slots, n_loose, radius = sc.bvh()
+    wide = sc.wide_bvh()
+    if len(nodes) == 0 or nodes[0]["count"] > 0:
+        assert len(wide) == 0
+        return
+    if may_be_dropped and len(wide) == 0:      # a tree so lopsided that the wide walk could outgrow its stack: binary walk
+        return
+    assert len(wide) > 0
+    leaf_box = {}
+    stack = [0]
+    while stack:
+        nd = nodes[stack.pop()]
+        if nd["count"]:
+            leaf_box[(int(nd["first"]), int(nd["count"]))] = (nd["lo"].copy(), nd["hi"].copy())
+        else:
+            stack += [int(nd["first"]), int(nd["first"]) + 1]
+    seen, visited, stack = {}, 0, [0]
+    while stack:
+        w = wide[stack.pop()]
+        visited += 1
+        kids = [k for k in range(4) if w["ref"][k] != 0xFFFFFFFF]
+        assert len(kids) >= 2 and kids == list(range(len(kids)))          # filled from the front, never a lone child
+        for k in kids:
+            ref = int(w["ref"][k])
+            if ref >> 28:
+                key = (ref & 0x0FFFFFFF, ref >> 28)
+                assert key not in seen
+                seen[key] = True
+                lo, hi = leaf_box[key]
+                assert np.array_equal(w["lo"][:, k], lo) and np.array_equal(w["hi"][:, k], hi)
+            else:
+                assert 0 < ref < len(wide)
+                stack.append(ref)
+    assert visited == len(wide) and set(seen) == set(leaf_box)
+
+
 @pytest.mark.parametrize("max_leaf", [1, 2, 4])
 def test_bvh_structure(oracle, max_leaf):
     for name, _ in SHIPPED:
-        check_bvh(capi.Scene.load_json(os.path.join(SCENES, name + ".json"), max_leaf=max_leaf), oracle)
+        sc = capi.Scene.load_json(os.path.join(SCENES, name + ".json"), max_leaf=max_leaf)
+        check_bvh(sc, oracle)
+        check_wide(sc)
     prims = S.mixed_field(n_side=40, seed=5)
     sc = capi.Scene.create(prims, max_leaf=max_leaf)
+    check_wide(sc)
     d = check_bvh(sc, oracle)
     assert d < 31
     assert sc.info().n_prims == len(prims)
@@ -179,6 +222,7 @@ def test_bvh_depth_is_bounded_on_adversarial_input(oracle):
     p["q"][:, 3:6] = (2.0 ** (np.arange(n) / 40.0))[:, None] * 0.4
     sc = capi.Scene.create(p, max_leaf=1)
     assert check_bvh(sc, oracle) <= 31
+    check_wide(sc, may_be_dropped=True)
     n = 70
     p = S.new_prims(n)
     p["kind"] = S.SPHERE
@@ -186,11 +230,12 @@ def test_bvh_depth_is_bounded_on_adversarial_input(oracle):
     p["q"][:, 3:6] = (3.0 ** np.arange(n))[:, None] * 0.3
     sc = capi.Scene.create(p, max_leaf=1)
     assert check_bvh(sc, oracle) <= 31
+    check_wide(sc, may_be_dropped=True)
 
 
 def oracle_bvh(oracle, sc):
     nodes, slots, n_slots, n_loose, radius = sc.bvh()
-    return oracle.bvh(nodes, slots, n_slots, n_loose, radius)
+    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh())      # walked the way the kernels walk it
 
 
 @pytest.mark.parametrize("name,cam_id", SHIPPED)
