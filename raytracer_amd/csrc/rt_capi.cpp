@@ -581,6 +581,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.texels = ctx->d_texels; d.tex_table = ctx->d_tex_table;
     d.n_textures = static_cast<uint32_t>(scene->tex_table.size());
     d.nodes4 = reinterpret_cast<const float4*>(ctx->d_nodes4);
+    d.root_ref = scene->wide_root_ref;
     for (int k = 0; k < 3; ++k) { d.root_lo[k] = 0.0f; d.root_hi[k] = 0.0f; }
     if (ctx->d_nodes4) for (int k = 0; k < 3; ++k) { d.root_lo[k] = scene->nodes[0].lo[k]; d.root_hi[k] = scene->nodes[0].hi[k]; }
     d.inst = ctx->d_inst; d.n_inst = static_cast<uint32_t>(scene->inst_recs.size());

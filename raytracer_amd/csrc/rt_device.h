@@ -27,7 +27,8 @@ struct DevScene {
     const uint8_t*     texels;     // albedo textures, 8-bit RGB
     const rt_tex_rec*  tex_table;
     const float4*      nodes4;     // wide nodes (8 x 16 bytes each), or null: walk the binary nodes
-    float root_lo[3], root_hi[3];  // wide walk: the root's box (wide node 0 holds the root's children)
+    float root_lo[3], root_hi[3];  // wide walk: the root's box ...
+    uint32_t root_ref;             // ... and where the walk goes once inside it: a wide node, or the leaf the root is
     const rt_inst_rec* inst;       // two-level scenes: instances in the leaf order of the top-level tree
     uint32_t n_inst;
     uint32_t n_nodes, n_slots, n_loose, n_lights, n_prims, n_textures;

@@ -420,10 +420,10 @@ struct Walker {
         limit_f = f32_up(limit);
         cur = REF_NONE;
         if (WIDE) {
-            // the root's box travels with the kernel arguments; wide node 0 holds the root's children
+            // the root's box travels with the kernel arguments, with the wide node that holds the root's children
             if (COUNT) vn += 1;
             if (box_entry(make_float4(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2], 0.0f), make_float4(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2], 0.0f),
-                          br, limit_f) != __builtin_inff()) cur = 0u;
+                          br, limit_f) != __builtin_inff()) cur = sc.root_ref;
         } else if (sc.n_nodes) {
             const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
             const float4 lo = nodes[0], hi = nodes[1];
@@ -1222,7 +1222,7 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
         else          hipLaunchKernelGGL((k_rays<0, false, R, I, W>), grid, block, 0, st, *sc, *cam, *pm, n_tiles, 0u, n_rays, ids, dist, FB, ctr, queue, refill_min); \
     } while (0)
 #define RT_LAUNCH_PRIMARY_I(R, FB, I)                                                                                                    \
-    do { if (!(I) && sc->nodes4) RT_LAUNCH_PRIMARY_IW(R, FB, false, true); else RT_LAUNCH_PRIMARY_IW(R, FB, I, false); } while (0)
+    do { if (sc->nodes4) RT_LAUNCH_PRIMARY_IW(R, FB, I, true); else RT_LAUNCH_PRIMARY_IW(R, FB, I, false); } while (0)
 #define RT_LAUNCH_SURFACE(F, I) hipLaunchKernelGGL((k_surface<F, I>), dim3((n_tiles + 3u) / 4u), dim3(256), 0, st, *sc, *cam, *pm, n_tiles, *fb)
     if (sc->inst) {                     // two-level scene (no textures there)
         switch (variant) {
@@ -1254,18 +1254,14 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
                                        uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                                        const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t n_rays = n_tiles * n_batch * 64u;
-    if (sc->inst) {
-        if (counting) hipLaunchKernelGGL((k_rays<1, true, 0, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<1, false, 0, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
-        return hipGetLastError();
-    }
-    if (sc->nodes4) {
-        if (counting) hipLaunchKernelGGL((k_rays<1, true, 0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
-        else          hipLaunchKernelGGL((k_rays<1, false, 0, false, true>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
-        return hipGetLastError();
-    }
-    if (counting) hipLaunchKernelGGL((k_rays<1, true, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
-    else          hipLaunchKernelGGL((k_rays<1, false, 0>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);
+#define RT_LAUNCH_SHADOW(I, W)                                                                                                           \
+    do {                                                                                                                                 \
+        if (counting) hipLaunchKernelGGL((k_rays<1, true, 0, I, W>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min);  \
+        else          hipLaunchKernelGGL((k_rays<1, false, 0, I, W>), dim3(n_waves), dim3(64), 0, st, *sc, *cam, *pm, n_tiles, light0, n_rays, nullptr, nullptr, *fb, ctr, queue, refill_min); \
+    } while (0)
+    if (sc->inst) { if (sc->nodes4) RT_LAUNCH_SHADOW(true, true); else RT_LAUNCH_SHADOW(true, false); }
+    else          { if (sc->nodes4) RT_LAUNCH_SHADOW(false, true); else RT_LAUNCH_SHADOW(false, false); }
+#undef RT_LAUNCH_SHADOW
     return hipGetLastError();
 }
 
@@ -1290,9 +1286,8 @@ extern "C" hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, c
             else          hipLaunchKernelGGL((k_trace_rays<false, false, I, W>), dim3(nb), dim3(64), 0, st, *sc, rays, n, ids, dist, rgb, records, ctr);\
         }                                                                                                                                          \
     } while (0)
-    if (sc->inst) RT_LAUNCH_TRACE(true, false);
-    else if (sc->nodes4) RT_LAUNCH_TRACE(false, true);
-    else RT_LAUNCH_TRACE(false, false);
+    if (sc->inst) { if (sc->nodes4) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
+    else          { if (sc->nodes4) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
 #undef RT_LAUNCH_TRACE
     return hipGetLastError();
 }
@@ -1306,7 +1301,8 @@ extern "C" hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec*
 extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
                                            uint8_t* rgb, rt_counters* ctr) {
     const uint32_t nb = static_cast<uint32_t>((n + 63) / 64);
-    if (nb && sc->inst)        hipLaunchKernelGGL((k_shade_hits<true, false>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    if (nb && sc->inst && sc->nodes4) hipLaunchKernelGGL((k_shade_hits<true, true>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
+    else if (nb && sc->inst)   hipLaunchKernelGGL((k_shade_hits<true, false>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
     else if (nb && sc->nodes4) hipLaunchKernelGGL((k_shade_hits<false, true>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
     else if (nb)               hipLaunchKernelGGL((k_shade_hits<false, false>), dim3(nb), dim3(64), 0, st, *sc, hits, view, n, rgb, ctr);
     return hipGetLastError();

@@ -33,7 +33,7 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
         cls[i] = static_cast<uint8_t>(rt_make_record(p, static_cast<uint32_t>(i), rec[i], box[i]));
     }
 
-    struct MeshTree { rt_box64 bounds; bool empty = true; uint32_t root_ref = 0, depth = 0; float radius = 0.0f; bool built = false; };
+    struct MeshTree { rt_box64 bounds; bool empty = true; uint32_t root_ref = 0, wide_root_ref = 0, depth = 0; float radius = 0.0f; bool built = false; };
     std::map<std::pair<uint32_t, uint32_t>, MeshTree> meshes;
     uint64_t id_total = 0;
     for (const rt_instance& in : s->instances) {
@@ -89,7 +89,11 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
     rt_bvh_result top;
     rt_build_bvh(inst_boxes, 1, bins, top);
     s->nodes = top.nodes;
+    // the same trees as wide nodes, one array: the top-level tree's first, each mesh's behind it; references are made
+    // absolute as the pieces are appended.  wide_need = stack entries the wide walk can need (both levels and the marker)
     s->nodes4.clear();
+    uint32_t wide_need = rt_collapse_wide(top.nodes, s->nodes4), wide_mesh_need = 0;
+    s->wide_root_ref = (!top.nodes.empty() && top.nodes[0].count) ? (top.nodes[0].count << 28) | top.nodes[0].first : 0u;
     s->recs.clear(); s->slot_prim.clear();
     uint32_t mesh_depth = 0;
     for (auto& kv : meshes) {
@@ -111,6 +115,20 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
         s->nodes[node_base + 1] = t.nodes[1];                // the unused slot beside the root stays an inverted box
         const rt_node32& root = s->nodes[node_base];
         m.root_ref = root.count ? (root.count << 28) | root.first : (root.first >> 1);
+        {
+            std::vector<rt_node4> w4;
+            wide_mesh_need = std::max(wide_mesh_need, rt_collapse_wide(t.nodes, w4));
+            const uint32_t base4 = static_cast<uint32_t>(s->nodes4.size());
+            m.wide_root_ref = root.count ? m.root_ref : base4;
+            for (rt_node4 w : w4) {
+                for (int k = 0; k < 4; ++k) {
+                    if (w.ref[k] == 0xFFFFFFFFu) continue;
+                    if (w.ref[k] >> 28) w.ref[k] = (w.ref[k] & 0xF0000000u) | ((w.ref[k] & 0x0FFFFFFFu) + slot_base);
+                    else w.ref[k] += base4;
+                }
+                s->nodes4.push_back(w);
+            }
+        }
         m.depth = t.depth;
         mesh_depth = std::max(mesh_depth, t.depth);
         for (uint32_t slot = 0; slot < t.order.size(); ++slot) {
@@ -126,12 +144,15 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
         rt_inst_rec r; std::memset(&r, 0, sizeof(r));
         for (int a = 0; a < 9; ++a) r.rot[a] = in.rot[a];
         for (int a = 0; a < 3; ++a) r.trans[a] = in.trans[a];
-        r.root_ref = m.root_ref;
+        r.root_ref = m.root_ref; r.pad[0] = m.wide_root_ref;      // the wide one replaces it below when the scene goes wide
         r.id_off = static_cast<int32_t>(static_cast<int64_t>(id_base[k]) - static_cast<int64_t>(in.first_prim));
         r.radius = m.radius;
         r.index = k;
         s->inst_recs.push_back(r);
     }
+    if (s->nodes4.size() >= (1ull << 28) || wide_need + 1 + wide_mesh_need >= RT_STACK_DEPTH_INST - 1) s->nodes4.clear();
+    if (!s->nodes4.empty()) for (rt_inst_rec& r : s->inst_recs) r.root_ref = r.pad[0];
+    for (rt_inst_rec& r : s->inst_recs) r.pad[0] = 0;
     s->n_slots = s->recs.size(); s->n_loose = 0;
     s->device_build = false; s->boxes_f32.clear();
 
@@ -227,7 +248,7 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
         rt_build_bvh(boxes, max_leaf, bins, bvh);
     }
     s->nodes.swap(bvh.nodes);
-    s->nodes4.clear();
+    s->nodes4.clear(); s->wide_root_ref = 0;
     if (!s->device_build && rt_collapse_wide(s->nodes, s->nodes4) >= RT_STACK_DEPTH_INST - 1) s->nodes4.clear();   // too lopsided for the wide walk's stack
     s->n_slots = bounded_recs.size();
     s->n_loose = loose.size();

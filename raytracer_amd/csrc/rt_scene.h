@@ -20,6 +20,7 @@ struct rt_scene {
     std::vector<rt_prim_rec>  recs;                  // BVH slot order, then the loose primitives
     std::vector<rt_node32>    nodes;                 // node 0 = root, node 1 unused, sibling pairs at even indices
     std::vector<rt_node4>     nodes4;                // the same tree collapsed into wide nodes (empty: walk the binary one)
+    uint32_t wide_root_ref = 0;                      // where the wide walk starts: wide node 0, or the leaf the root is
     std::vector<uint32_t>     slot_prim;             // slot -> id (bounded, BVH order; loose ones appended)
     uint64_t n_slots = 0, n_loose = 0;
     rt_scene_info info{};
