@@ -202,6 +202,11 @@ int rt_ctx_build_time(rt_ctx* ctx, double* ms_out);
 int rt_ctx_download_bvh(rt_ctx* ctx, rt_node32* nodes_out, uint32_t node_capacity, uint32_t* n_nodes_out,
                         uint32_t* slot_prim_out, uint64_t slot_capacity, uint64_t* n_slots_out);
 
+/* The wide nodes the kernels walk on this GPU, if they walk any (n = 0 otherwise): for a host-built scene what
+ * rt_scene_get_wide_bvh returns; for a device-built one 2 * n_slots places of which place i holds the wide form of inner
+ * node i of the binary tree (place 0: the root; places of leaves are unused). */
+int rt_ctx_download_wide_bvh(rt_ctx* ctx, rt_node4* nodes4_out, uint32_t capacity, uint32_t* n_nodes4_out);
+
 /* RayTracer::get_one_ray_per_pixel + one_pass_intersection over a pixel rectangle (raytracer.cpp:123-157):
  * primary rays generated in registers, closest hit.  Outputs row-major in the rectangle; either may be NULL. */
 int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* hit_id_dev, double* dist_dev);

@@ -102,6 +102,7 @@ SYMBOLS = [
     ("rt_scene_upload", C.c_int, [_VP, _VP]),
     ("rt_ctx_build_time", C.c_int, [_VP, C.POINTER(_D)]),
     ("rt_ctx_download_bvh", C.c_int, [_VP, _VP, _U32, C.POINTER(_U32), _VP, _U64, C.POINTER(_U64)]),
+    ("rt_ctx_download_wide_bvh", C.c_int, [_VP, _VP, _U32, C.POINTER(_U32)]),
     ("rt_trace_primary", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP, _VP]),
     ("rt_trace_rays", C.c_int, [_VP, _VP, _U64, _VP, _VP]),
     ("rt_shade_rays", C.c_int, [_VP, _VP, _U64, _VP]),
@@ -384,6 +385,15 @@ class Context:
         slots = np.zeros(ns.value, dtype=np.uint32)
         _check(lib().rt_ctx_download_bvh(self.h, _ptr(nodes), len(nodes), C.byref(nn), _ptr(slots), len(slots), C.byref(ns)))
         return nodes, slots
+
+    def download_wide_bvh(self):
+        """The wide nodes the kernels walk on this GPU (NODE4_DT), empty when they walk the binary tree."""
+        n = C.c_uint32()
+        _check(lib().rt_ctx_download_wide_bvh(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=NODE4_DT)
+        if n.value:
+            _check(lib().rt_ctx_download_wide_bvh(self.h, _ptr(out), n.value, C.byref(n)))
+        return out
 
     def set_counting(self, on):
         _check(lib().rt_ctx_set_counting(self.h, 1 if on else 0))

@@ -49,7 +49,9 @@ struct rt_ctx {
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
     uint8_t* d_texels = nullptr; rt_tex_rec* d_tex_table = nullptr;
-    rt_node4* d_nodes4 = nullptr;          // wide nodes of host-built scenes
+    rt_node4* d_nodes4 = nullptr;          // wide nodes (host-built: collapsed on the host; device-built: written by the builder)
+    uint32_t n_nodes4_dev = 0;
+    bool dev_wide = false; uint32_t dev_root_ref = 0; float dev_root_lo[3] = {}, dev_root_hi[3] = {};   // device-built scenes
     rt_inst_rec* d_inst = nullptr;         // two-level scenes
     uint32_t* d_slot_prim = nullptr;       // slot -> primitive id, as uploaded or as the device build ordered it
     uint32_t n_nodes_dev = 0; uint64_t n_slots_dev = 0;
@@ -478,7 +480,11 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
     const uint32_t n = static_cast<uint32_t>(scene->n_slots);
     const size_t total = scene->recs.size();                 // bounded, then unbounded
     rt_prim_rec* d_in = nullptr; float* d_boxes = nullptr; uint32_t* d_order = nullptr; void* d_work = nullptr;
+    uint8_t* d_need = nullptr;
     size_t work_bytes = 0;
+    // wide nodes beside the binary ones (wide node i = inner node i of the binary tree) while their references fit
+    const bool want_wide = n >= 2 && n <= (1u << 27);
+    ctx->dev_root_ref = 0; ctx->dev_wide = false;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int rc = RT_OK;
     auto check = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
@@ -490,6 +496,9 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_nodes), 2ull * n * sizeof(rt_node32)), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_recs), total * sizeof(rt_prim_rec)), "hipMalloc");
     if (rc == RT_OK) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_slot_prim), total * sizeof(uint32_t)), "hipMalloc");
+    if (rc == RT_OK && want_wide) check(hipMalloc(reinterpret_cast<void**>(&ctx->d_nodes4), 2ull * n * sizeof(rt_node4)), "hipMalloc");
+    if (rc == RT_OK && want_wide) check(hipMalloc(reinterpret_cast<void**>(&d_need), 2ull * n), "hipMalloc");
+    if (rc == RT_OK && want_wide) check(hipMemsetAsync(d_need, 0, 2ull * n, ctx->stream), "hipMemsetAsync");
     if (rc == RT_OK) check(hipMemcpy(d_in, scene->recs.data(), total * sizeof(rt_prim_rec), hipMemcpyHostToDevice), "hipMemcpy");
     if (rc == RT_OK) check(hipMemcpy(d_boxes, scene->boxes_f32.data(), scene->boxes_f32.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
     if (rc == RT_OK) check(hipMemcpy(ctx->d_slot_prim, scene->slot_prim.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy");
@@ -502,7 +511,8 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
         check(hipEventCreate(&t0), "hipEventCreate"); check(hipEventCreate(&t1), "hipEventCreate");
         if (rc == RT_OK) {
             (void)hipEventRecord(t0, ctx->stream);
-            check(rt_device_build(ctx->stream, n, d_boxes, bounds, d_in, ctx->d_nodes, ctx->d_recs, d_order, d_work, work_bytes), "device build");
+            check(rt_device_build(ctx->stream, n, d_boxes, bounds, d_in, ctx->d_nodes, ctx->d_recs, d_order, d_work, work_bytes,
+                                  want_wide ? ctx->d_nodes4 : nullptr, d_need), "device build");
             // the unbounded primitives follow the sorted ones unchanged; slot -> id of the sorted part comes from the records
             if (rc == RT_OK && total > n)
                 check(hipMemcpyAsync(ctx->d_recs + n, d_in + n, (total - n) * sizeof(rt_prim_rec), hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
@@ -511,10 +521,19 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
             check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
             float ms = 0.0f;
             if (rc == RT_OK && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) ctx->build_ms = ms;
+            // the root's box for the kernel arguments, and whether the wide walk fits the traversal stack
+            rt_node32 root{};
+            if (rc == RT_OK) check(hipMemcpy(&root, ctx->d_nodes, sizeof(root), hipMemcpyDeviceToHost), "hipMemcpy");
+            uint8_t need0 = 255;
+            if (rc == RT_OK && want_wide) check(hipMemcpy(&need0, d_need, 1, hipMemcpyDeviceToHost), "hipMemcpy");
+            for (int k = 0; k < 3; ++k) { ctx->dev_root_lo[k] = root.lo[k]; ctx->dev_root_hi[k] = root.hi[k]; }
+            ctx->dev_wide = rc == RT_OK && want_wide && root.count == 0 && need0 < RT_STACK_DEPTH_INST - 1;
         }
     }
     if (t0) (void)hipEventDestroy(t0);
     if (t1) (void)hipEventDestroy(t1);
+    if (!ctx->dev_wide && ctx->d_nodes4) { (void)hipFree(ctx->d_nodes4); ctx->d_nodes4 = nullptr; }
+    if (d_need) (void)hipFree(d_need);
     if (d_work) (void)hipFree(d_work);
     if (d_order) (void)hipFree(d_order);
     if (d_boxes) (void)hipFree(d_boxes);
@@ -548,6 +567,18 @@ int rt_ctx_download_bvh(rt_ctx* ctx, rt_node32* nodes_out, uint32_t node_capacit
     return RT_OK;
 }
 
+int rt_ctx_download_wide_bvh(rt_ctx* ctx, rt_node4* nodes4_out, uint32_t capacity, uint32_t* n_nodes4_out) {
+    if (int rc = need_scene(ctx)) return rc;
+    const uint32_t n = ctx->d_nodes4 ? ctx->n_nodes4_dev : 0u;
+    if (n_nodes4_out) *n_nodes4_out = n;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (nodes4_out && n) {
+        if (capacity < n) return fail(RT_ERR_LIMIT, "wide node buffer too small");
+        RT_HIP(hipMemcpy(nodes4_out, ctx->d_nodes4, static_cast<size_t>(n) * sizeof(rt_node4), hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
 int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (!scene) return fail(RT_ERR_INVALID, "null scene");
     if (int rc = use(ctx)) return rc;
@@ -568,7 +599,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (rc == RT_OK) rc = upload(scene->texels, &ctx->d_texels);
     if (rc == RT_OK) rc = upload(scene->tex_table, &ctx->d_tex_table);
     if (rc == RT_OK) rc = upload(scene->inst_recs, &ctx->d_inst);
-    if (rc == RT_OK) rc = upload(scene->nodes4, &ctx->d_nodes4);
+    if (rc == RT_OK && !scene->device_build) rc = upload(scene->nodes4, &ctx->d_nodes4);
     if (rc != RT_OK) { ctx->free_scene(); return rc; }
     DevScene& d = ctx->sc;
     d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
@@ -580,10 +611,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.n_prims = static_cast<uint32_t>(scene->prims.size());
     d.texels = ctx->d_texels; d.tex_table = ctx->d_tex_table;
     d.n_textures = static_cast<uint32_t>(scene->tex_table.size());
+    ctx->n_nodes4_dev = !ctx->d_nodes4 ? 0u : (scene->device_build ? 2u * static_cast<uint32_t>(scene->n_slots) : static_cast<uint32_t>(scene->nodes4.size()));
     d.nodes4 = reinterpret_cast<const float4*>(ctx->d_nodes4);
     d.root_ref = scene->wide_root_ref;
     for (int k = 0; k < 3; ++k) { d.root_lo[k] = 0.0f; d.root_hi[k] = 0.0f; }
-    if (ctx->d_nodes4) for (int k = 0; k < 3; ++k) { d.root_lo[k] = scene->nodes[0].lo[k]; d.root_hi[k] = scene->nodes[0].hi[k]; }
+    if (ctx->d_nodes4 && !scene->device_build) for (int k = 0; k < 3; ++k) { d.root_lo[k] = scene->nodes[0].lo[k]; d.root_hi[k] = scene->nodes[0].hi[k]; }
+    if (ctx->d_nodes4 && scene->device_build) { for (int k = 0; k < 3; ++k) { d.root_lo[k] = ctx->dev_root_lo[k]; d.root_hi[k] = ctx->dev_root_hi[k]; } d.root_ref = 0; }
     d.inst = ctx->d_inst; d.n_inst = static_cast<uint32_t>(scene->inst_recs.size());
     // round the radius up: the padding must not shrink through the conversion
     d.radius = std::nextafterf(static_cast<float>(scene->info.radius), INFINITY);

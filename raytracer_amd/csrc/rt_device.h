@@ -102,7 +102,8 @@ hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const De
 hipError_t rt_launch_bounce_fold(hipStream_t st, const DevScene* sc, const LevelBufs* lv, size_t n, uint8_t* rgb);
 hipError_t rt_device_build_workspace(uint32_t n, size_t* bytes);
 hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* boxes, const float bounds[6], const rt_prim_rec* recs_in,
-                           rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out, void* work, size_t work_bytes);
+                           rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out, void* work, size_t work_bytes,
+                           rt_node4* wide_out, uint8_t* wide_need);
 hipError_t rt_launch_slot_ids(hipStream_t st, const rt_prim_rec* recs, uint32_t n, uint32_t* slot_prim);
 hipError_t rt_launch_assemble(hipStream_t st, int width, int height, int tile, int tiles_x, int n_ranks, int tiles_per_rank,
                               const uint8_t* gathered, uint8_t* frame);

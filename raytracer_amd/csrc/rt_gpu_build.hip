@@ -102,15 +102,53 @@ __global__ void __launch_bounds__(256) k_split_level(const unsigned long long* _
     }
 }
 
-// Boxes of one level's inner nodes: the union of the two children, which are already in place.
+__device__ inline float box_area(const rt_node32& nd) {
+    const float ex = nd.hi[0] - nd.lo[0], ey = nd.hi[1] - nd.lo[1], ez = nd.hi[2] - nd.lo[2];
+    return ex*ey + ey*ez + ez*ex;
+}
+
+// Boxes of one level's inner nodes: the union of the two children, which are already in place.  With `wide` set, the
+// node's wide form is written as well (wide node = its index in the binary tree): its two children, the inner one with
+// the larger box replaced by its own children, twice - everything below this level is final by now.  need[i] = stack
+// entries a wide walk below node i can need.
 __global__ void __launch_bounds__(256) k_fit_level(uint32_t level, const uint4* __restrict__ items, const uint32_t* __restrict__ off,
-                                                   const uint32_t* __restrict__ cnt, rt_node32* __restrict__ nodes) {
+                                                   const uint32_t* __restrict__ cnt, rt_node32* __restrict__ nodes,
+                                                   rt_node4* __restrict__ wide, uint8_t* __restrict__ need) {
     const uint32_t begin = off[level], count = cnt[level];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
         const uint32_t node = items[begin + i].x;
         const uint32_t pair = nodes[node].first;
         const rt_node32 l = nodes[pair], r = nodes[pair + 1];
         for (int k = 0; k < 3; ++k) { nodes[node].lo[k] = fminf(l.lo[k], r.lo[k]); nodes[node].hi[k] = fmaxf(l.hi[k], r.hi[k]); }
+        if (!wide) continue;
+        uint32_t ch[4] = { pair, pair + 1u, 0u, 0u };
+        rt_node32 cn[4]; cn[0] = l; cn[1] = r;
+        int nch = 2;
+        while (nch < 4) {
+            int best = -1; float best_area = -1.0f;
+            for (int k = 0; k < nch; ++k) if (cn[k].count == 0u) { const float a = box_area(cn[k]); if (a > best_area) { best_area = a; best = k; } }
+            if (best < 0) break;
+            const uint32_t f = cn[best].first;
+            ch[best] = f; cn[best] = nodes[f];
+            ch[nch] = f + 1u; cn[nch] = nodes[f + 1u];
+            ++nch;
+        }
+        rt_node4 w;
+        uint32_t deepest = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (k < nch) {
+                for (int a = 0; a < 3; ++a) { w.lo[a][k] = cn[k].lo[a]; w.hi[a][k] = cn[k].hi[a]; }
+                if (cn[k].count) w.ref[k] = (cn[k].count << 28) | cn[k].first;
+                else { w.ref[k] = ch[k]; deepest = max(deepest, static_cast<uint32_t>(need[ch[k]])); }
+            } else {
+                for (int a = 0; a < 3; ++a) { w.lo[a][k] = __builtin_inff(); w.hi[a][k] = -__builtin_inff(); }
+                w.ref[k] = 0xFFFFFFFFu;
+            }
+            w.pad[k] = 0u;
+        }
+        wide[node] = w;
+        const uint32_t nd = static_cast<uint32_t>(nch - 1) + deepest;
+        need[node] = static_cast<uint8_t>(nd > 255u ? 255u : nd);
     }
 }
 
@@ -161,9 +199,12 @@ extern "C" hipError_t rt_device_build_workspace(uint32_t n, size_t* bytes) {
 
 // boxes: 6 floats per primitive (lo xyz, hi xyz), already rounded outward; bounds: union of all boxes.
 // nodes_out holds 2 n nodes, recs_out and order_out n entries, work rt_device_build_workspace(n) bytes; all device memory.
+// wide_out (2 n wide nodes) and wide_need (2 n bytes) may be null: then only the binary tree is made.  Otherwise
+// wide_out[i] is the wide form of inner node i (node 0: the root) and wide_need[0] the stack a wide walk can need.
 // Launches only: nothing is allocated and the stream is not synchronised.
 extern "C" hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* boxes, const float bounds[6], const rt_prim_rec* recs_in,
-                                      rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out, void* work, size_t work_bytes) {
+                                      rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out, void* work, size_t work_bytes,
+                                      rt_node4* wide_out, uint8_t* wide_need) {
     if (n == 0) return hipSuccess;
     size_t temp_bytes = 0;
     hipError_t e = sort_temp_bytes(n, temp_bytes);
@@ -203,7 +244,7 @@ extern "C" hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* b
                 for (uint32_t level = 0; level < kLevels; ++level)
                     hipLaunchKernelGGL(k_split_level, dim3(blocks_l), dim3(256), 0, st, keys_out, order_out, boxes, level, items, off, cnt, nodes_out);
                 for (uint32_t level = kLevels; level-- > 0;)
-                    hipLaunchKernelGGL(k_fit_level, dim3(blocks_l), dim3(256), 0, st, level, items, off, cnt, nodes_out);
+                    hipLaunchKernelGGL(k_fit_level, dim3(blocks_l), dim3(256), 0, st, level, items, off, cnt, nodes_out, wide_out, wide_need);
             }
             hipLaunchKernelGGL(k_pad_node, dim3(1), dim3(1), 0, st, nodes_out);
             e = hipGetLastError();

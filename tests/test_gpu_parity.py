@@ -592,7 +592,10 @@ def test_hierarchy_built_on_the_device(ctx, oracle, name, cam_id):
     # node / primitive fetch counts of the device-built tree: GPU counting kernels == CPU walk of the downloaded tree
     prims, lights = sc.prims(), sc.lights()
     radius = float(np.nextafter(np.float32(info.radius), np.float32(np.inf)))
-    b = oracle.bvh(nodes, slots, info.n_slots, info.n_loose, radius)
+    wide = ctx.download_wide_bvh()
+    if info.n_slots >= 2:
+        assert len(wide) == 2 * info.n_slots                # the builder wrote wide nodes beside the binary ones
+    b = oracle.bvh(nodes, slots, info.n_slots, info.n_loose, radius, wide)
     _, _, counts, hits = oracle.bvh_render(oracle.scene(prims, lights), b, ocamera(cam))
     ctx.set_counting(True); ctx.reset_counters()
     ctx.render(cam, max_scatters=0)
