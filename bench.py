@@ -217,7 +217,8 @@ def main():
     tm = ctx.timing()
     ctx.set_timing(False)
     # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights and per bounce level
-    kname, k_ms, k_bytes = ("k_rays<1,false,0,true>" if args.instanced else "k_rays<1,false,0,false>") + " (shadow pass)", tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
+    wide = args.device_build or scene.n_wide() > 0
+    kname, k_ms, k_bytes = "k_rays<1,false,0,%s,%s> (shadow pass)" % ("true" if args.instanced else "false", "true" if wide else "false"), tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
         bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
     by_kind = [int(v) for v in info.n_by_kind]
     prim_flops = sum(PRIM_FLOPS.get(k, 0) * n for k, n in enumerate(by_kind)) / max(sum(by_kind), 1)
@@ -257,6 +258,7 @@ def main():
                             "1M-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
                             % (W, H, len(lights)),
                 "n_side": args.n_side, "n_prims": int(info.n_instanced_prims if args.instanced else info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
+                "wide_nodes": (2 * int(info.n_slots) if ctx.build_time_ms() > 0 else scene.n_wide()),
                 "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
                 "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
@@ -264,7 +266,7 @@ def main():
                 "shadow_rays": total["shadow_rays"], "bounce_rays": total["bounce_rays"], "scene_build_s": round(build_s, 3),
                 "hierarchy": "Morton order cut top-down at the highest differing key bit, built on the GPU in %.2f ms" % ctx.build_time_ms() if args.device_build
                              else ("binned SAH on the host: one tree over the instances, one per mesh" if args.instanced else "binned SAH, built on the host"),
-                "arithmetic": "FP32 padded-box traversal, FP64 leaf tests and shading",
+                "arithmetic": "FP32 padded-box traversal through 4-wide nodes, FP64 leaf tests and shading",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNEL = "k_rays<1, false, 0, false>"
+SHADOW = "k_rays<1, false, 0,"      # the plain (non-counting) shadow launch, whichever tree variant the workload runs
 
 
 def mean_counter(path, counter):
@@ -26,6 +26,7 @@ def main(src, dst):
     fetch, nf = mean_counter(os.path.join(src, "fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
     write, nw = mean_counter(os.path.join(src, "write", "write_counter_collection.csv"), "WRITE_SIZE")
     bench = json.loads(open(os.path.join(src, "fetch_bench.json")).read().strip().splitlines()[-1])
+    KERNEL = max((k for k in fetch if k.startswith(SHADOW)), key=lambda k: fetch[k])
     out = {
         "kernel": KERNEL,
         "workload": {k: bench["config"][k] for k in ("n_side", "n_prims", "rays_per_frame", "max_scatters")},

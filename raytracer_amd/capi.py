@@ -322,6 +322,12 @@ class Scene:
             slots = np.frombuffer((C.c_char * (total * 4)).from_address(ps.value), dtype=np.uint32).copy()
         return nodes, slots, int(ns.value), int(info.n_loose), float(np.nextafter(np.float32(info.radius), np.float32(np.inf)))
 
+    def n_wide(self):
+        """Number of wide nodes (0: the kernels walk the binary tree)."""
+        n = C.c_uint32()
+        _check(lib().rt_scene_get_wide_bvh(self.h, None, C.byref(n)))
+        return int(n.value)
+
     def wide_bvh(self):
         """The wide nodes the kernels walk (NODE4_DT), empty when the scene is walked through the binary tree."""
         p, n = C.c_void_p(), C.c_uint32()
