@@ -137,13 +137,12 @@ template <int N> DEV void load_rec(const rt_prim_rec* rec, double (&c)[18]) {
 
 // One primitive record against one ray.  The three families (ellipsoid / planar / rotated-scaled box frame)
 // are laid out so that a wave holding a mix of kinds serialises only the family-specific middle part.
-template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, const RayD& r, HitD& h) {
+// c: the record's 18 doubles, already in registers (an ellipsoid uses the first 9).
+template <bool FULL, bool UV = false> DEV bool hit_loaded(const double (&c)[18], uint32_t kind, const RayD& r, HitD& h) {
     const double pi = 3.14159265358979323846;
-    double c[18];
     double px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0;
     if (kind == RT_SPHERE) {
         // Sphere::intersect (axis-aligned ellipsoid), mesh.cpp:597-642.  c: C[0..2], S[3..5], 1/S[6..8].
-        load_rec<9>(rec, c);
         const double ro0 = (r.ox - c[0]) * c[6], ro1 = (r.oy - c[1]) * c[7], ro2 = (r.oz - c[2]) * c[8];
         const double rd0 = r.dx * c[6], rd1 = r.dy * c[7], rd2 = r.dz * c[8];
         const double A = rd0*rd0 + rd1*rd1 + rd2*rd2;
@@ -176,7 +175,6 @@ template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec
         // Plane::intersect (parallelogram P0 + u e1 + v e2), mesh.cpp:855-886, and the triangle extension
         // (same frame, inside test u >= -eps, v >= -eps, u + v <= 1 + eps).
         // c: W = [e1 e2 n]^-1 row-major [0..8], P0[9..11], e1[12..14], e2[15..17].
-        load_rec<18>(rec, c);
         const double qx = r.ox - c[9], qy = r.oy - c[10], qz = r.oz - c[11];
         const double ro2 = c[6]*qx + c[7]*qy + c[8]*qz;
         const double rd2 = c[6]*r.dx + c[7]*r.dy + c[8]*r.dz;
@@ -208,7 +206,6 @@ template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec
     } else if (kind == RT_CUBE || kind == RT_CYLINDER) {
         // c: T[0..2], R[3..11] row-major, S[12..14], 1/S[15..17].  World ray into the unit frame
         // (mesh.cpp:171-180), local solve, local hit back to the world (mesh.cpp:223-233).
-        load_rec<18>(rec, c);
         double ro[3], rd[3], pl[3], nl[3] = { 0, 0, 0 };
         const double tx = r.ox - c[0], ty = r.oy - c[1], tz = r.oz - c[2];
 #pragma unroll
@@ -261,6 +258,13 @@ template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec
         h.px = px; h.py = py; h.pz = pz; h.nx = nx; h.ny = ny; h.nz = nz;
     }
     return true;
+}
+
+// The same with the record still in memory: fetches what the kind needs.
+template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec, uint32_t kind, const RayD& r, HitD& h) {
+    double c[18];
+    if (kind == RT_SPHERE) load_rec<9>(rec, c); else load_rec<18>(rec, c);
+    return hit_loaded<FULL, UV>(c, kind, r, h);
 }
 
 // ---- BVH traversal ---------------------------------------------------------------------------
@@ -389,11 +393,15 @@ struct Walker {
     uint32_t vn, vp;
 
     DEV void test_slot(const DevScene& sc, uint32_t slot) {
+        // kind and all 18 doubles in one go: waiting for the kind before asking for the numbers would put two trips
+        // to memory one behind the other, and a record is rarely in a cache
         const rt_prim_rec* rec = sc.recs + slot;
         const uint2 tag = *reinterpret_cast<const uint2*>(&rec->kind);
+        double c[18];
+        load_rec<18>(rec, c);
         if (COUNT) ++vp;
         HitD h;
-        if (!hit_record<false>(rec, tag.x, r, h)) return;
+        if (!hit_loaded<false>(c, tag.x, r, h)) return;
         if (MODE == 0) {
             const int32_t id = static_cast<int32_t>(tag.y) + (INST ? id_off : 0);
             if (h.dist < best.dist || (h.dist == best.dist && id < best.id)) {
@@ -793,8 +801,15 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     // XCDs): the waves behind one L2 work through neighbouring rays.  A wave whose run is used up helps with the others.
     const uint32_t n_chunks = static_cast<uint32_t>((static_cast<unsigned long long>(n_rays) + RT_CHUNK - 1) / RT_CHUNK);
     uint32_t q_part = blockIdx.x % RT_QUEUE_PARTS, q_tried = 0;
+#ifdef RT_PHASE_TIMING
+    unsigned long long pt_swap = 0, pt_inner = 0, pt_leaf = 0, pt_inner_it = 0, pt_inner_lanes = 0, pt_leaf_it = 0, pt_leaf_lanes = 0;
+    const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
+#endif
 
     for (;;) {
+#ifdef RT_PHASE_TIMING
+        const unsigned long long pt_t0 = __builtin_amdgcn_s_memtime();
+#endif
         const int n_trav = __popcll(__ballot(state == TRAV));
         const int n_done = __popcll(__ballot(state == DONE));
         const bool swap = n_trav == 0 || (q_empty ? n_done >= refill_min : 64 - n_trav >= refill_min);
@@ -883,6 +898,11 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
             if (__ballot(state == TRAV) == 0) continue;          // only finished rays on board: write them out first
         }
         // ---- one while-while round for the rays in flight ----------------------------------------------------------
+#ifdef RT_PHASE_TIMING
+        const unsigned long long pt_t1 = __builtin_amdgcn_s_memtime();
+        pt_swap += pt_t1 - pt_t0;
+        unsigned long long pt_t2 = pt_t1;
+#endif
         if (state == TRAV) {
             // Lanes step through inner nodes together; once fewer than a quarter of the rays in flight are still among
             // inner nodes the others test their leaves, and the stragglers resume in the next round (they would
@@ -890,18 +910,53 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
 #if RT_INNER_EXIT_REL > 0
             const int in_flight = __popcll(__ballot(true));
             while (w.at_internal()) {
+#ifdef RT_PHASE_TIMING
+                pt_inner_lanes += 1; if (lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(true))) - 1)) pt_inner_it += 1;
+#endif
                 w.step_internal(sc);
                 if (__popcll(__ballot(w.at_internal())) * RT_INNER_EXIT_REL < in_flight) break;
             }
-            if (!w.done() && !w.at_internal()) w.step_leaf(sc);
+#ifdef RT_PHASE_TIMING
+            pt_t2 = __builtin_amdgcn_s_memtime();
+#endif
+            if (!w.done() && !w.at_internal()) {
+#ifdef RT_PHASE_TIMING
+                pt_leaf_lanes += 1; if (lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(true))) - 1)) pt_leaf_it += 1;
+#endif
+                w.step_leaf(sc);
+            }
 #else
             while (w.at_internal()) w.step_internal(sc);
             if (!w.done()) w.step_leaf(sc);
 #endif
             if (w.done()) state = DONE;
         }
+#ifdef RT_PHASE_TIMING
+        {
+            // the lanes reconverge here; lane-dependent sums were taken inside divergent code by whichever lanes were there,
+            // so take the maximum over the wave afterwards (below)
+            const unsigned long long pt_t3 = __builtin_amdgcn_s_memtime();
+            const unsigned long long trav = __ballot(pt_t2 != pt_t1);
+            if (trav) pt_t2 = __shfl(pt_t2, __ffsll(static_cast<long long>(trav)) - 1);
+            pt_inner += pt_t2 - pt_t1; pt_leaf += pt_t3 - pt_t2;
+        }
+#endif
     }
     const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
+#ifdef RT_PHASE_TIMING
+    if (MODE == 1) {
+        // wave-level figures: every lane holds its own partial view of the divergent parts; reduce with max
+        const unsigned long long total = __builtin_amdgcn_s_memtime() - pt_begin;
+        const unsigned long long a = pt_swap, b = pt_inner, c = pt_leaf, d = wave_sum(pt_inner_it), e = wave_sum(pt_inner_lanes), f = wave_sum(pt_leaf_it), g = wave_sum(pt_leaf_lanes);
+        const bool l0 = lane == 0;
+        add_counter(ctr, shard, F_VN_P, l0 ? a : 0); add_counter(ctr, shard, F_VP_P, l0 ? b : 0); add_counter(ctr, shard, F_VN_S, l0 ? c : 0);
+        add_counter(ctr, shard, F_VP_S, l0 ? total : 0);
+        add_counter(ctr, shard, F_HITS, l0 ? d : 0); add_counter(ctr, shard, F_BOUNCE, l0 ? e : 0);
+        add_counter(ctr, shard, F_PRIMARY, l0 ? f : 0); add_counter(ctr, shard, F_SHADOW, l0 ? g : 0);
+        return;
+    }
+    return;
+#endif
     if (MODE == 0) {
         const bool bounce_level = (RECORD & 2) && fb.level > 0;
         add_counter(ctr, shard, bounce_level ? F_BOUNCE : F_PRIMARY, n_cast);
