@@ -376,7 +376,7 @@ DEV void hit_out_of_instance(const rt_inst_rec* in, HitD& h) {
 // "blocked iff the CLOSEST hit lies in (1e-4, light_dist - 1e-4)" (raytracer.cpp:230-235): hits at or
 // beyond light_dist - 1e-4 are irrelevant; once one hit inside the interval is known only hits at
 // <= 1e-4 can still change the verdict, so the search limit collapses to 1e-4; any such hit ends it.
-// vn counts node records fetched (1 for the root, 2 per internal node visited), vp primitive records.
+// vn counts node records fetched (1 for the root, 2 per internal node visited, 4 per wide node), vp primitive records.
 // WIDE: the scene carries wide nodes (four subtrees per node) and the walk goes through them.
 template <int MODE, bool COUNT, bool INST = false, bool WIDE = false>
 struct Walker {
@@ -416,11 +416,10 @@ struct Walker {
     }
 
     // Root box test; afterwards cur is the first node reference or REF_NONE.
-    DEV void start(const DevScene& sc, const RayD& ray, uint2* lds_stack, uint2* deep_stack, double ldist) {
+    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist) {
         r = ray;
         if (INST) { rw = ray; inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
-        (void)lds_stack;
         st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
@@ -521,11 +520,11 @@ struct Walker {
 
 // A whole walk in one go (arbitrary-ray and bounce kernels).
 template <int MODE, bool COUNT, bool INST = false, bool WIDE = false>
-DEV bool traverse(const DevScene& sc, const RayD& r, uint2* lds_stack, double light_dist,
+DEV bool traverse(const DevScene& sc, const RayD& r, double light_dist,
                   Best& best, uint32_t& vn, uint32_t& vp) {
     Walker<MODE, COUNT, INST, WIDE> w; w.vn = 0; w.vp = 0;
     DeepStack<INST || WIDE> deep;
-    w.start(sc, r, lds_stack, deep.e, light_dist);
+    w.start(sc, r, deep.e, light_dist);
     while (!w.done()) {
         // inner nodes: the wave stays here until every lane holds a leaf or has run out of nodes
         while (w.at_internal()) w.step_internal(sc);
@@ -613,12 +612,12 @@ DEV double light_value(const rt_light& L, const rt_mat_rec& m, double px, double
 template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
                       double nx, double ny, double nz, double view_ox, double view_oy, double view_oz,
-                      uint2* lds_stack, ShadeCounters& ctr) {
+                      ShadeCounters& ctr) {
     RayD sr;
     const double light_dist = shadow_ray(L, px, py, pz, nx, ny, nz, sr);
     Best b;
     ++ctr.shadow_rays;
-    if (traverse<1, COUNT, INST, WIDE>(sc, sr, lds_stack, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
+    if (traverse<1, COUNT, INST, WIDE>(sc, sr, light_dist, b, ctr.vn, ctr.vp)) return 0.0;
     return light_value(L, m, px, py, pz, nx, ny, nz, sr.dx, sr.dy, sr.dz, view_ox, view_oy, view_oz);
 }
 
@@ -655,13 +654,13 @@ DEV uint32_t finish_shade(const rt_mat_rec& m, uint32_t albedo, double lighting)
 // RayTracer::shade, raytracer.cpp:159-279, all lights in order inside one lane (megakernel path).
 template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec& m, uint32_t albedo, double view_ox, double view_oy,
-                            double view_oz, uint2* lds_stack, ShadeCounters& ctr) {
+                            double view_oz, ShadeCounters& ctr) {
     if (sc.n_lights == 0) return 0;
     double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);
     double lighting = 0.0;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const rt_light L = sc.lights[li];
-        lighting += light_term<COUNT, INST, WIDE>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, lds_stack, ctr);
+        lighting += light_term<COUNT, INST, WIDE>(sc, L, m, h.px, h.py, h.pz, nx, ny, nz, view_ox, view_oy, view_oz, ctr);
     }
     return finish_shade(m, albedo, lighting);
 }
@@ -669,9 +668,9 @@ DEV uint32_t shade_material(const DevScene& sc, const HitD& h, const rt_mat_rec&
 // h must carry u, v when the scene has textures.
 template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV uint32_t shade(const DevScene& sc, const HitD& h, int32_t id, double view_ox, double view_oy, double view_oz,
-                   uint2* lds_stack, ShadeCounters& ctr) {
+                   ShadeCounters& ctr) {
     const rt_mat_rec m = sc.mats[id];
-    return shade_material<COUNT, INST, WIDE>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, lds_stack, ctr);
+    return shade_material<COUNT, INST, WIDE>(sc, h, m, albedo_at(sc, m, h.u, h.v), view_ox, view_oy, view_oz, ctr);
 }
 
 // Camera::pixelToRay, persp_camera.cpp:94-118 (effective sensor size precomputed on the host).
@@ -789,7 +788,6 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint2* my_stack = nullptr;
     enum { IDLE = 0, TRAV = 1, DONE = 2 };
     uint32_t state = IDLE, out = 0, ridx = 0;
     Walker<MODE, COUNT, INST, WIDE> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
@@ -878,7 +876,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                 primary_ray(cam, p.x, p.y, r);
                             }
                             if (have) {
-                                w.start(sc, r, my_stack, deep.e, 0.0);
+                                w.start(sc, r, deep.e, 0.0);
                                 ++n_cast;
                                 state = w.done() ? DONE : TRAV;
                             }
@@ -886,7 +884,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                             const rt_light L = sc.lights[light0 + g / n_tiles];
                             RayD r;
                             const double ld = shadow_ray(L, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out], r);
-                            w.start(sc, r, my_stack, deep.e, ld);
+                            w.start(sc, r, deep.e, ld);
                             ++n_cast;
                             state = w.done() ? DONE : TRAV;
                         }
@@ -1045,7 +1043,6 @@ template <bool COUNT, bool SHADE, bool INST = false, bool WIDE = false>
 __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __restrict__ rays, uint64_t n,
                                                    int32_t* __restrict__ ids, double* __restrict__ dist,
                                                    uint8_t* __restrict__ rgb, double* __restrict__ records, rt_counters* ctr) {
-    uint2* my_stack = nullptr;
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
     bool hit = false;
     uint32_t vn = 0, vp = 0;
@@ -1056,7 +1053,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
         r.dx = rays[i*6 + 3]; r.dy = rays[i*6 + 4]; r.dz = rays[i*6 + 5];
         r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
         Best b;
-        hit = traverse<0, COUNT, INST, WIDE>(sc, r, my_stack, 0.0, b, vn, vp);
+        hit = traverse<0, COUNT, INST, WIDE>(sc, r, 0.0, b, vn, vp);
         if (ids) ids[i] = b.id;
         if (dist) dist[i] = b.dist;
         if (records) {      // the Hit of the reference (utils.h:68-112): 16 doubles per ray
@@ -1076,7 +1073,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
                 HitD h; h.u = 0.0; h.v = 0.0;
                 int32_t mat_id;
                 best_record<true, INST>(sc, b, r, h, mat_id);
-                c = shade<COUNT, INST, WIDE>(sc, h, mat_id, r.ox, r.oy, r.oz, my_stack, sctr);
+                c = shade<COUNT, INST, WIDE>(sc, h, mat_id, r.ox, r.oy, r.oz, sctr);
             }
             rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
         }
@@ -1129,13 +1126,13 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
             const rt_mat_rec m = sc.mats[static_cast<int32_t>(idf)];
             // a texture is only consulted when the Hit carries surface coordinates (mesh.cpp:23)
             const uint32_t alb = (hits[i*10 + 9] != 0.0) ? albedo_at(sc, m, h.u, h.v) : solid_albedo(m);
-            c = shade_material<false, INST, WIDE>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            c = shade_material<false, INST, WIDE>(sc, h, m, alb, view[i*3], view[i*3 + 1], view[i*3 + 2], sctr);
         } else if (idf == -2.0) {
             // a hit that names no primitive: white, non-metallic, roughness 0.5 (raytracer.cpp:204-208, 250-254, 268-272)
             rt_mat_rec m;
             m.metallic = 0.0; m.roughness = 0.5; m.ior = 1.5; m.albedo[0] = 255; m.albedo[1] = 255; m.albedo[2] = 255;
             m.tex = -1;
-            c = shade_material<false, INST, WIDE>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], nullptr, sctr);
+            c = shade_material<false, INST, WIDE>(sc, h, m, 0x00FFFFFFu, view[i*3], view[i*3 + 1], view[i*3 + 2], sctr);
         }
         rgb[i*3] = c & 255u; rgb[i*3 + 1] = (c >> 8) & 255u; rgb[i*3 + 2] = (c >> 16) & 255u;
     }
