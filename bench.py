@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak
+L1_PATH_PEAK_GBS = 64 * 256 * 2.4          # bytes per clock and CU x CUs x GHz
 NODE_BYTES, PRIM_BYTES = 32, 64
 # algorithmic flops: a slab test (6 sub, 6 mul, 12 min/max, 6 compares), a primitive test by kind (cube / cylinder: two
 # 3x3 matrix-vector products and slabs or a quadratic; ellipsoid; plane / triangle)
@@ -278,6 +279,9 @@ def main():
                 # the secondary bound: algorithmic flops of the same launch against the FP32 vector peak
                 "fp32": {"achieved": k_flops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": k_flops / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": k_flops},
+                # the path every load takes into a CU's L1 (texture addresser): 64 bytes per clock and CU (the CDNA3 figure,
+                # assumed unchanged), 256 CUs at 2.4 GHz - the counters show this path about four fifths busy
+                "l1_path": {"achieved": achieved, "peak": L1_PATH_PEAK_GBS, "unit": "GB/s", "frac": achieved / L1_PATH_PEAK_GBS},
                 # what a frame must read and write at least once: every node and record, 3 bytes per pixel
                 "compulsory_bytes_per_frame": NODE_BYTES * int(info.n_nodes) + PRIM_BYTES * int(info.n_slots + info.n_loose) + 3 * W * H,
                 "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,

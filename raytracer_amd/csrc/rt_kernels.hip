@@ -833,31 +833,39 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 state = IDLE;
             }
             // ---- fresh rays for the free lanes ---------------------------------------------------------------
+            // next chunk of the wave's run of the chunk sequence (or of the other runs, once that one is used up)
+            auto fetch_chunk = [&](uint32_t& c_next, uint32_t& c_end) -> bool {
+                while (q_tried < RT_QUEUE_PARTS) {
+                    const uint32_t p0 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * q_part / RT_QUEUE_PARTS);
+                    const uint32_t p1 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * (q_part + 1) / RT_QUEUE_PARTS);
+                    unsigned int c = 0;
+                    if (lane == 0) c = atomicAdd(queue + q_part, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    if (c < p1 - p0) {
+                        c_next = (p0 + c) * RT_CHUNK;
+                        c_end = (n_rays - c_next < RT_CHUNK) ? n_rays : c_next + RT_CHUNK;
+                        return true;
+                    }
+                    q_part = (q_part + 1) % RT_QUEUE_PARTS; ++q_tried;
+                }
+                return false;
+            };
             while (!q_empty) {
                 const unsigned long long idle = __ballot(state == IDLE);
                 if (!idle) break;
-                if (q_next == q_end) {
-                    bool got = false;
-                    uint32_t chunk = 0;
-                    while (q_tried < RT_QUEUE_PARTS) {
-                        const uint32_t p0 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * q_part / RT_QUEUE_PARTS);
-                        const uint32_t p1 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * (q_part + 1) / RT_QUEUE_PARTS);
-                        unsigned int c = 0;
-                        if (lane == 0) c = atomicAdd(queue + q_part, 1u);
-                        c = __builtin_amdgcn_readfirstlane(c);
-                        if (c < p1 - p0) { chunk = p0 + c; got = true; break; }
-                        q_part = (q_part + 1) % RT_QUEUE_PARTS; ++q_tried;
-                    }
-                    if (!got) { q_empty = true; break; }
-                    q_next = chunk * RT_CHUNK;
-                    q_end = (n_rays - q_next < RT_CHUNK) ? n_rays : q_next + RT_CHUNK;
-                }
-                const uint32_t avail = q_end - q_next, n_idle = static_cast<uint32_t>(__popcll(idle));
-                const uint32_t take = n_idle < avail ? n_idle : avail;
+                if (q_next == q_end && !fetch_chunk(q_next, q_end)) { q_empty = true; break; }
+                // when the rest of the chunk cannot fill the free lanes the next chunk is opened in the same pass: the
+                // set-up below is long, and running it twice for one swap (once per chunk) is what this avoids
+                const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+                const uint32_t take_a = n_idle < q_end - q_next ? n_idle : q_end - q_next;
+                uint32_t b_next = 0, b_end = 0;
+                if (take_a < n_idle && !fetch_chunk(b_next, b_end)) q_empty = true;
+                const uint32_t take_b = n_idle - take_a < b_end - b_next ? n_idle - take_a : b_end - b_next;
+                const uint32_t take = take_a + take_b;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
                 if (state == IDLE && rank < take) {
-                    ridx = q_next + rank;
+                    ridx = rank < take_a ? q_next + rank : b_next + (rank - take_a);
                     const uint32_t g = ridx >> 6;
                     const Pixel p = map_pixel(pm, MODE == 0 ? g : g % n_tiles, ridx & 63u);
                     if (p.valid) {
@@ -890,7 +898,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         }
                     }
                 }
-                q_next += take;
+                if (b_end != b_next) { q_next = b_next + take_b; q_end = b_end; } else q_next += take_a;
             }
             if (__ballot(state != IDLE) == 0) { if (q_empty) break; else continue; }
             if (__ballot(state == TRAV) == 0) continue;          // only finished rays on board: write them out first
