@@ -164,10 +164,12 @@ int rt_scene_get_prims(const rt_scene* scene, const rt_prim_desc** prims, uint64
 int rt_scene_get_lights(const rt_scene* scene, const rt_light** lights, uint32_t* n);
 int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n_nodes,
                      const uint32_t** slot_prim, uint64_t* n_slots);
-/* The hierarchy as the kernels walk it for host-built, non-instanced scenes: the binary tree collapsed into wide nodes
- * (one 128-byte fetch and four box tests per step instead of two steps; the same boxes, the same leaves).  n = 0 when
- * the scene is walked through the binary nodes (device-built, instanced, a single leaf, or a tree so lopsided that the
- * wide walk could need more than the traversal stack holds). */
+/* The hierarchy as the kernels walk it for host-built scenes: the binary tree collapsed into wide nodes (one 128-byte
+ * fetch and four box tests per step instead of two steps; the same boxes, the same leaves).  For a two-level scene one
+ * array holds the tree over the instances first and then each mesh's tree, inner references counted from the start of
+ * the array.  n = 0 when the scene is walked through the binary nodes (a single leaf, or a tree so lopsided that the
+ * wide walk could need more than the traversal stack holds) and for device-built scenes (see rt_ctx_download_wide_bvh).
+ * The reference has no counterpart (its tree is binary, raytracer.cpp:454-499). */
 int rt_scene_get_wide_bvh(const rt_scene* scene, const rt_node4** nodes4, uint32_t* n_nodes4);
 /* Camera by id as read_all_cameras builds it (raytracer.cpp:29-68); RT_ERR_NOT_FOUND if absent.
  * index >= 0 with id == NULL enumerates cameras in file order; id_out (>= 32 bytes) may be NULL. */
