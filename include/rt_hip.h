@@ -232,6 +232,18 @@ int rt_shade_hits(rt_ctx* ctx, const double* hits10_dev, const double* view3_dev
  * rect.w * rect.h * 3 bytes; hit_id_dev (may be NULL) receives the primary hit ids. */
 int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
                    uint8_t* rgb_dev, int32_t* hit_id_dev);
+/* rt_render_rect with max_scatters = 0 for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The frame working
+ * set (80 bytes per pixel: hit points, normals, light sums, record slots, shadow verdicts) and the work-queue heads
+ * live in a fixed workspace compiled into the library - a __device__ array of RT_STATIC_MAX_PIXELS * 80 + 4096 bytes
+ * (20 MiB), of which every GPU the library runs on holds its own copy until the process ends - so the call makes no
+ * hipMalloc / hipFree and calls no allocating routine.  Limit: rect.w * rect.h <= RT_STATIC_MAX_PIXELS (262144, e.g.
+ * 512 x 512); larger rectangles return RT_ERR_LIMIT - render them in pieces.  Launch timing (rt_ctx_set_timing)
+ * must be off (RT_ERR_INVALID otherwise: it creates events).  All calls on one GPU share that GPU's workspace: calls
+ * that overlap in time on one GPU (two contexts, two streams) race; calls ordered on one stream do not, and each call
+ * clears what it needs cleared.  Outputs are byte-identical to rt_render_rect's. */
+#define RT_STATIC_MAX_PIXELS 262144u
+int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* rgb_dev, int32_t* hit_id_dev);
 /* The same loop with samples_per_pixel > 1 (raytracer.cpp:403-436): sample 0 through the pixel centre, later samples
  * offset by up to half a pixel; per-sample linear 8-bit colours are averaged, rounded, then gamma encoded.  The
  * reference seeds its offsets from std::random_device, so frames differ run to run; here they are a pure function

@@ -58,7 +58,8 @@ struct rt_ctx {
     double build_ms = 0.0;
     uint8_t* d_gamma = nullptr;            // 256 bytes of the display transfer table, then 256 bytes of identity
     unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
-    uint32_t queue_used = kQueueSlots;     // slots consumed since the last zeroing
+    void* static_scratch = nullptr;        // this GPU's copy of the library's fixed workspace (rt_render_rect_static)
+    size_t static_scratch_bytes = 0;
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
     int refill_min = RT_REFILL_MIN;
     // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
@@ -376,6 +377,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
             if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_min = v; }
         }
     }
+    // this GPU's address of the library's fixed workspace, looked up once per device with the device current
+    if (e == hipSuccess) e = rt_static_scratch(device, &c->static_scratch, &c->static_scratch_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_gamma), 512);
     if (e == hipSuccess) {
         uint8_t lut[512]; rt_gamma_table(lut);
@@ -629,14 +632,23 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
 
 namespace {
 
+// Work-queue heads of one pipeline call: kQueueSlots counters, RT_QUEUE_PARTS per persistent launch.  A call starts
+// with `used` at the end, so its first launch zeroes the block: a captured or replayed sequence must not depend on
+// what earlier calls left there.
+struct QueueBlock {
+    unsigned int* base;
+    uint32_t used = kQueueSlots;
+    explicit QueueBlock(unsigned int* b) : base(b) {}
+};
+
 // A zeroed work-queue head for the next persistent launch (the block of heads is re-zeroed when it runs out).
-int next_queue(rt_ctx* ctx, unsigned int** q) {
-    if (ctx->queue_used >= kQueueSlots) {
-        RT_HIP(hipMemsetAsync(ctx->d_queue, 0, kQueueSlots * sizeof(unsigned int), ctx->stream));
-        ctx->queue_used = 0;
+int next_queue(rt_ctx* ctx, QueueBlock& qb, unsigned int** q) {
+    if (qb.used >= kQueueSlots) {
+        RT_HIP(hipMemsetAsync(qb.base, 0, kQueueSlots * sizeof(unsigned int), ctx->stream));
+        qb.used = 0;
     }
-    *q = ctx->d_queue + ctx->queue_used;
-    ctx->queue_used += RT_QUEUE_PARTS;
+    *q = qb.base + qb.used;
+    qb.used += RT_QUEUE_PARTS;
     return RT_OK;
 }
 
@@ -649,20 +661,29 @@ uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
     return static_cast<uint32_t>(want < ctx->max_waves ? want : ctx->max_waves);
 }
 
-// Carve the frame working set out of the context's grow-only scratch (allocated on first use of a size).
-int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
-    const size_t planes = 7;
-    void* base = nullptr;
-    if (int rc = ctx->need(3, n * (planes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + n_batch) + 256, &base)) return rc;
+// The frame working set of n output slots laid over a block of memory: 7 planes of doubles, four of 32-bit words, one
+// verdict byte per slot and light of a batch.
+constexpr size_t kFramePlanes = 7;
+size_t frame_bytes(size_t n, uint32_t n_batch) {
+    return n * (kFramePlanes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + n_batch) + 256;
+}
+void carve_frame(void* base, size_t n, bool textures, FrameBufs& fb) {
     double* d = static_cast<double*>(base);
     fb.px = d; fb.py = d + n; fb.pz = d + 2*n; fb.nx = d + 3*n; fb.ny = d + 4*n; fb.nz = d + 5*n;
     fb.lighting = d + 6*n;
-    fb.id = reinterpret_cast<int32_t*>(d + planes * n);
+    fb.id = reinterpret_cast<int32_t*>(d + kFramePlanes * n);
     fb.n = n;
     fb.ray = nullptr; fb.rawn = nullptr; fb.alive = nullptr; fb.level = 0;
-    fb.albedo = ctx->sc.n_textures ? reinterpret_cast<uint32_t*>(fb.id + n) : nullptr;
+    fb.albedo = textures ? reinterpret_cast<uint32_t*>(fb.id + n) : nullptr;
     fb.slot = reinterpret_cast<uint32_t*>(fb.id + 2 * n); fb.inst = fb.slot + n;
     fb.lit = reinterpret_cast<uint8_t*>(fb.id + 4 * n);
+}
+
+// The same out of the context's grow-only scratch (allocated on first use of a size).
+int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
+    void* base = nullptr;
+    if (int rc = ctx->need(3, frame_bytes(n, n_batch), &base)) return rc;
+    carve_frame(base, n, ctx->sc.n_textures != 0, fb);
     return RT_OK;
 }
 
@@ -690,18 +711,18 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
     lv.last = reinterpret_cast<uint8_t*>(lv.tint + static_cast<size_t>(max_scatters) * n_out);
     fb.alive = lv.last + n_out;
     if (pm.mode == 1) RT_HIP(hipMemsetAsync(fb.id, 0xFF, n_out * sizeof(int32_t), ctx->stream));
-    ctx->queue_used = kQueueSlots;
+    QueueBlock qb(ctx->d_queue);
     for (int level = 0; level <= max_scatters; ++level) {
         fb.level = level;
         unsigned int* q = nullptr;
-        if (int rc = next_queue(ctx, &q)) return rc;
+        if (int rc = next_queue(ctx, qb, &q)) return rc;
         ctx->mark_begin(0);
         RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting,
                                  level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill_min));
         ctx->mark_end();
         for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
             const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
-            if (int rc = next_queue(ctx, &q)) return rc;
+            if (int rc = next_queue(ctx, qb, &q)) return rc;
             ctx->mark_begin(1);
             RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                     ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
@@ -718,25 +739,24 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
     return RT_OK;
 }
 
-// Primary pass, shadow pass per light batch, resolve: the max_scatters = 0 frame.
-int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out,
-                 uint8_t* rgb_dev, int32_t* hit_id_dev) {
+// Primary pass, shadow pass per light batch, resolve: the max_scatters = 0 frame, on a working set and a block of
+// queue heads the caller provides.  Allocates nothing unless launch timing is on (events).
+int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out,
+                    uint8_t* rgb_dev, int32_t* hit_id_dev, FrameBufs& fb, unsigned int* queue_heads) {
     const uint32_t n_lights = ctx->sc.n_lights;
     const uint32_t batch = n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH;
-    FrameBufs fb;
-    if (int rc = frame_bufs(ctx, n_out, batch, fb)) return rc;
     if (pm.mode == 1)   // padded slots of edge tiles and of a short last round: no primitive
         RT_HIP(hipMemsetAsync(fb.id, 0xFF, n_out * sizeof(int32_t), ctx->stream));
-    ctx->queue_used = kQueueSlots;      // a captured or replayed sequence must not depend on earlier calls: always re-zero
+    QueueBlock qb(queue_heads);
     unsigned int* q = nullptr;
-    if (int rc = next_queue(ctx, &q)) return rc;
+    if (int rc = next_queue(ctx, qb, &q)) return rc;
     ctx->mark_begin(0);
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
                              &fb, ctx->d_ctr, q, ctx->refill_min));
     ctx->mark_end();
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
-        if (int rc = next_queue(ctx, &q)) return rc;
+        if (int rc = next_queue(ctx, qb, &q)) return rc;
         ctx->mark_begin(1);
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
@@ -748,6 +768,14 @@ int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t 
     return RT_OK;
 }
 
+int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out,
+                 uint8_t* rgb_dev, int32_t* hit_id_dev) {
+    const uint32_t n_lights = ctx->sc.n_lights;
+    FrameBufs fb;
+    if (int rc = frame_bufs(ctx, n_out, n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH, fb)) return rc;
+    return run_pipeline_on(ctx, dc, pm, n_waves, n_out, rgb_dev, hit_id_dev, fb, ctx->d_queue);
+}
+
 } // namespace
 
 int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* hit_id_dev, double* dist_dev) {
@@ -756,9 +784,9 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
     PixelMap pm; uint32_t nw = 0;
     if (int rc = rect_map(cam, rect, pm, nw)) return rc;
     DevCamera dc; to_dev_camera(*cam, dc);
-    ctx->queue_used = kQueueSlots;
+    QueueBlock qb(ctx->d_queue);
     unsigned int* q = nullptr;
-    if (int rc = next_queue(ctx, &q)) return rc;
+    if (int rc = next_queue(ctx, qb, &q)) return rc;
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, dist_dev, nullptr,
                              ctx->d_ctr, q, ctx->refill_min));
     return RT_OK;
@@ -854,9 +882,9 @@ int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatter
         // no lights: the reference writes an all-black frame without tracing (raytracer.cpp:387-395)
         RT_HIP(hipMemsetAsync(rgb_dev, 0, n_out * 3, ctx->stream));
         if (hit_id_dev) {
-            ctx->queue_used = kQueueSlots;
+            QueueBlock qb(ctx->d_queue);
             unsigned int* q = nullptr;
-            if (int rc = next_queue(ctx, &q)) return rc;
+            if (int rc = next_queue(ctx, qb, &q)) return rc;
             RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
                                      ctx->d_ctr, q, ctx->refill_min));
         }
@@ -867,6 +895,38 @@ int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatter
 }
 
 } // namespace
+
+int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* rgb_dev, int32_t* hit_id_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !rgb_dev) return fail(RT_ERR_INVALID, "bad camera or null output");
+    PixelMap pm; uint32_t nw = 0;
+    if (int rc = rect_map(cam, rect, pm, nw)) return rc;
+    const size_t n_out = static_cast<size_t>(rect.w) * rect.h;
+    const uint32_t n_lights = ctx->sc.n_lights;
+    const uint32_t batch = n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH;
+    const size_t queue_bytes = (kQueueSlots * sizeof(unsigned int) + 255u) & ~static_cast<size_t>(255);
+    if (n_out > RT_STATIC_MAX_PIXELS || queue_bytes + frame_bytes(n_out, batch) > ctx->static_scratch_bytes)
+        return fail(RT_ERR_LIMIT, "rt_render_rect_static: rectangle of " + std::to_string(n_out) + " pixels exceeds the fixed workspace (at most "
+                                  + std::to_string(RT_STATIC_MAX_PIXELS) + " pixels per call); render it in pieces or use rt_render_rect");
+    if (ctx->timing) return fail(RT_ERR_INVALID, "rt_render_rect_static: launch timing creates events; switch it off (rt_ctx_set_timing)");
+    DevCamera dc; to_dev_camera(*cam, dc);
+    if (n_lights == 0) {        // the reference's all-black frame (raytracer.cpp:387-395); ids on request
+        RT_HIP(hipMemsetAsync(rgb_dev, 0, n_out * 3, ctx->stream));
+        if (hit_id_dev) {
+            QueueBlock qb(static_cast<unsigned int*>(ctx->static_scratch));
+            unsigned int* q = nullptr;
+            if (int rc = next_queue(ctx, qb, &q)) return rc;
+            RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
+                                     ctx->d_ctr, q, ctx->refill_min));
+        }
+        return RT_OK;
+    }
+    // queue heads first (zeroed by the pipeline's first launch), then the frame working set; every plane a launch reads
+    // is written earlier in the same call, so what the previous call left in the workspace is never seen
+    FrameBufs fb;
+    carve_frame(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes, n_out, ctx->sc.n_textures != 0, fb);
+    return run_pipeline_on(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev, fb, static_cast<unsigned int*>(ctx->static_scratch));
+}
 
 int32_t rt_tile_count(rt_tiling t) {
     if (t.tile <= 0 || t.width <= 0 || t.height <= 0) return 0;

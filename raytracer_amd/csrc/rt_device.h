@@ -17,6 +17,7 @@
 #define RT_QUEUE_PARTS 8u          // work-queue heads per launch: one per XCD
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
 #define RT_REFILL_MIN 40           // finished lanes that must pile up before a wave swaps rays (default)
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * 80u + 4096u)  // its workspace: 80 bytes per pixel + the queue heads
 
 struct DevScene {
     const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
@@ -105,6 +106,9 @@ hipError_t rt_device_build(hipStream_t st, uint32_t n, const float* boxes, const
                            rt_node32* nodes_out, rt_prim_rec* recs_out, uint32_t* order_out, void* work, size_t work_bytes,
                            rt_node4* wide_out, uint8_t* wide_need);
 hipError_t rt_launch_slot_ids(hipStream_t st, const rt_prim_rec* recs, uint32_t n, uint32_t* slot_prim);
+// Address and size, on the current device, of the library's fixed workspace (a file-scope __device__ array in
+// rt_kernels.hip; every GPU holds its own copy at its own address).  `device` must be the current device.
+hipError_t rt_static_scratch(int device, void** ptr, size_t* bytes);
 hipError_t rt_launch_assemble(hipStream_t st, int width, int height, int tile, int tiles_x, int n_ranks, int tiles_per_rank,
                               const uint8_t* gathered, uint8_t* frame);
 }

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "rt_device.h"
 
 #define DEV __device__ __forceinline__
@@ -1241,6 +1243,29 @@ __global__ void __launch_bounds__(256) k_assemble_tiles(int width, int height, i
 }
 
 // ---- host-callable launchers (called from rt_capi.cpp) ---------------------------------------------
+
+// Fixed workspace of rt_render_rect_static: the frame working set and the queue heads of one call, for callers that
+// must not allocate.  The array's name is a host-side handle, not a device address: host code asks the runtime for
+// this GPU's address once per device and uses that pointer everywhere (kernel arguments, hipMemsetAsync).
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+extern "C" hipError_t rt_static_scratch(int device, void** ptr, size_t* bytes) {
+    constexpr int kMaxDevices = 64;
+    static void* per_device[kMaxDevices] = {};
+    static std::mutex guard;
+    if (!ptr || !bytes || device < 0 || device >= kMaxDevices) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(guard);
+    if (!per_device[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        per_device[device] = p;
+    }
+    *ptr = per_device[device];
+    *bytes = sizeof(scratch);
+    return hipSuccess;
+}
 
 // Multi-sample frames: per-sample linear 8-bit colours are summed per channel, and the mean is rounded and gamma
 // encoded once (raytracer.cpp:419-436).
