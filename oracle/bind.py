@@ -52,7 +52,8 @@ class _Texture(C.Structure):
 class _Scene(C.Structure):
     _fields_ = [("prims", C.c_void_p), ("n_prims", C.c_int64), ("lights", C.c_void_p), ("n_lights", C.c_int64),
                 ("textures", C.c_void_p), ("n_textures", C.c_int64), ("prim_tex", C.c_void_p),
-                ("instanced", C.c_int64), ("inst", C.c_void_p), ("n_inst", C.c_int64), ("inst_bounds", C.c_void_p)]
+                ("instanced", C.c_int64), ("inst", C.c_void_p), ("n_inst", C.c_int64), ("inst_bounds", C.c_void_p),
+                ("prim_bounds", C.c_void_p)]
 
 
 def new_prims(n):
@@ -91,6 +92,9 @@ class Oracle:
         L.rto_render.argtypes = [C.POINTER(_Scene), C.POINTER(Camera)] + [C.c_int] * 4 + \
                                 [C.c_int, C.c_double, vp, i64p, i64p, C.c_int]
         L.rto_gamma_lut.argtypes = [vp]
+        L.rto_trace_rays_rgb.argtypes = [C.POINTER(_Scene), vp, C.c_int64, C.c_int, C.c_double, vp, C.c_int]
+        L.rto_hit_bounds.argtypes = [vp, C.c_int64, vp]
+        L.rto_brute_shade_rays.argtypes = [C.POINTER(_Scene), vp, C.c_int64, vp, vp, vp, C.c_int]
         L.rto_bvh_closest_hit.argtypes = [C.POINTER(_Scene), C.POINTER(Bvh), dp, dp, vp, i64p]
         L.rto_bvh_closest_hit.restype = C.c_int
         L.rto_bvh_occluded.argtypes = [C.POINTER(_Scene), C.POINTER(Bvh), dp, dp, C.c_double, i64p]
@@ -105,7 +109,7 @@ class Oracle:
         """textures: list of (h, w, 3) uint8 arrays; prim_tex: texture index per primitive (-1 = none)."""
         prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, LIGHT_DT), dtype=LIGHT_DT)
-        s = _Scene(_ptr(prims), len(prims), _ptr(lights), len(lights), None, 0, None, 0, None, 0, None)
+        s = _Scene(_ptr(prims), len(prims), _ptr(lights), len(lights), None, 0, None, 0, None, 0, None, None)
         s._keep = (prims, lights)
         if textures:
             arrs = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
@@ -115,6 +119,25 @@ class Oracle:
             s.textures, s.n_textures, s.prim_tex = C.cast(table, C.c_void_p), len(arrs), _ptr(pt)
             s._keep += (arrs, table, pt)
         return s
+
+    def with_prim_bounds(self, scene):
+        """Hand the brute-force loop a box per primitive so that it can pass over primitives a ray cannot touch;
+        results do not depend on it."""
+        prims = scene._keep[0]
+        bounds = np.empty((len(prims), 6), dtype=np.float64)
+        self.lib.rto_hit_bounds(_ptr(prims), len(prims), _ptr(bounds))
+        scene.prim_bounds = _ptr(bounds)
+        scene._keep += (bounds,)
+        return scene
+
+    def brute_shade_rays(self, scene, rays6, threads=0):
+        """Closest hit, shadow verdict per light and linear colour per ray, every ray against every primitive."""
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        hits = np.zeros(len(rays6), dtype=HIT_DT)
+        lit = np.zeros((len(rays6), max(int(scene.n_lights), 1)), dtype=np.uint8)
+        rgb = np.zeros((len(rays6), 3), dtype=np.uint8)
+        self.lib.rto_brute_shade_rays(C.byref(scene), _ptr(rays6), len(rays6), _ptr(hits), _ptr(lit), _ptr(rgb), threads)
+        return hits, lit[:, :int(scene.n_lights)], rgb
 
     def _hit_bounds(self, p):
         """Box that holds every point the intersector can return for p (the reference's own AABB of a plane spans the
@@ -198,6 +221,13 @@ class Oracle:
         rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
         out = np.zeros((len(rays6), 3), dtype=np.uint8)
         self.lib.rto_shade_rays(C.byref(scene), _ptr(rays6), len(rays6), _ptr(out), threads)
+        return out
+
+    def trace_rays_rgb(self, scene, rays6, max_scatters=2, min_scatter_intensity=0.0, threads=0):
+        """trace_ray_recursive per ray: linear 8-bit colour after up to max_scatters bounces (no gamma)."""
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros((len(rays6), 3), dtype=np.uint8)
+        self.lib.rto_trace_rays_rgb(C.byref(scene), _ptr(rays6), len(rays6), max_scatters, min_scatter_intensity, _ptr(out), threads)
         return out
 
     def trace_primary(self, scene, cam, rect=None, threads=0):
@@ -305,6 +335,11 @@ class Ref:
         L.ref_intersect_prim.argtypes = [C.c_int, vp, vp, C.c_long, vp]
         L.ref_prim_aabb.argtypes = [C.c_int, vp, vp]
         L.ref_camera_rays.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_long, vp]
+        L.ref_prims_create.argtypes = [vp, vp, C.c_long]
+        L.ref_prims_create.restype = vp
+        L.ref_prims_free.argtypes = [vp]
+        L.ref_prims_trace_bvh.argtypes = [vp, vp, C.c_long, vp, vp, C.c_int]
+        L.ref_prims_trace_brute.argtypes = [vp, vp, C.c_long, vp, vp, C.c_int]
         L.ref_time_one_pass.argtypes = [C.c_char_p, C.c_char_p]
         L.ref_time_one_pass.restype = C.c_double
         L.ref_time_accelerated.argtypes = [C.c_char_p, C.c_char_p]
@@ -364,6 +399,35 @@ class Ref:
         out = np.empty(6, dtype=np.float64)
         self.lib.ref_prim_aabb(refkind, _ptr(params), _ptr(out))
         return out
+
+    def prims_create(self, prims):
+        """A reference scene from PRIM_DT records (cubes, planes, cylinders, spheres only, already in that order),
+        built through the reference's public constructors."""
+        prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
+        kinds = np.ascontiguousarray(prims["kind"], dtype=np.int32)
+        assert (np.diff(kinds) >= 0).all() and kinds.max(initial=0) <= SPHERE
+        q = np.ascontiguousarray(prims["q"], dtype=np.float64)
+        h = self.lib.ref_prims_create(_ptr(kinds), _ptr(q), len(prims))
+        assert h
+        return h
+
+    def prims_free(self, h):
+        self.lib.ref_prims_free(h)
+
+    def _prims_trace(self, fn, h, rays6, threads):
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float64).reshape(-1, 6)
+        ids = np.empty(len(rays6), dtype=np.int32)
+        dist = np.empty(len(rays6), dtype=np.float64)
+        fn(h, _ptr(rays6), len(rays6), _ptr(ids), _ptr(dist), threads)
+        return ids, dist
+
+    def prims_trace_bvh(self, h, rays6, threads=1):
+        """(ids, distances) through the reference's own get_BVH_tree + accelerated_one_pass_intersection."""
+        return self._prims_trace(self.lib.ref_prims_trace_bvh, h, rays6, threads)
+
+    def prims_trace_brute(self, h, rays6, threads=1):
+        """(ids, distances) through the loop of one_pass_intersection over the same objects."""
+        return self._prims_trace(self.lib.ref_prims_trace_brute, h, rays6, threads)
 
     def camera_rays(self, path, cam_id, pxy):
         pxy = np.ascontiguousarray(pxy, dtype=np.float64).reshape(-1, 2)

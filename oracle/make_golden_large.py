@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""Fixtures at the benchmark configurations' sizes, independent of the product's hierarchy.  TEST INFRASTRUCTURE ONLY.
+
+    python oracle/make_golden_large.py config3 [--pixels 65536] [--threads 6]
+    python oracle/make_golden_large.py config4 [--pixels 16384]
+    python oracle/make_golden_large.py config5 [--pixels 65536]
+    python oracle/make_golden_large.py config3_ref_bvh          (needs oracle/_ref: development container only)
+
+config3 / config4: the 1M-cell mixed scene (raytracer_amd/scenes.py::mixed_field, seed 0x100000) at 3840x2160 /
+7680x4320, a seeded sample of pixels.  Every sampled primary ray and every shadow ray cast from its hit is resolved
+by the oracle's brute-force loop over ALL 1.33 M primitives in ascending id order (rto_brute_shade_rays: the
+algorithm of RayTracer::one_pass_intersection, s2899221/Code/raytracer.cpp:143-157, and of the shadow test in
+RayTracer::shade, raytracer.cpp:210-240); no tree is involved, the product's least of all.  Stored: pixel, closest-hit
+id, FP64 distance, one bit per light (set = the light reaches the point), linear 8-bit colour.
+
+config5: 10 000 instances of a 10 008-triangle mesh, every material a mirror, 3840x2160, two bounces; the oracle's
+loop over all instances and mesh primitives (inst_closest_hit) through rto_trace's recursion.  Stored: pixel, primary
+id, linear 8-bit colour after two bounces.  Instancing has no reference counterpart, so this fixture pins the product
+to the oracle only.
+
+config3_ref_bvh: the same million cells with parallelograms as reference Planes, built through the reference's public
+constructors and traced through the reference's OWN hierarchy (get_BVH_tree + accelerated_one_pass_intersection,
+raytracer.cpp:454-551) for every pixel of the 3840x2160 frame: valid for primary rays because the camera is outside
+the scene's bounds.  Stored: the id plane (int32, zlib) - the parallelogram ids map to the product's triangle pairs.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import bind                      # noqa: E402
+from raytracer_amd import scenes as S        # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sample_pixels(seed, W, H, n):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, W, n).astype(np.uint16), rng.integers(0, H, n).astype(np.uint16)
+
+
+def mixed(name, res, n_pixels, seed, threads):
+    W, H = res
+    O = bind.Oracle()
+    prims = S.mixed_field(n_side=1000, seed=0x100000)
+    lights = S.mixed_field_lights()
+    camd = S.mixed_field_camera(res=res)
+    cam = bind.camera_from_dict(O, camd)
+    px, py = sample_pixels(seed, W, H, n_pixels)
+    rays = O.pixel_rays(cam, np.stack([px + 0.5, py + 0.5], axis=1))
+    sc = O.with_prim_bounds(O.scene(prims, lights))
+    t0 = time.time()
+    hits, lit, rgb = O.brute_shade_rays(sc, rays, threads=threads)
+    dt = time.time() - t0
+    # the bounds only let the loop pass over primitives: the first 512 rays again without them
+    plain = O.scene(prims, lights)
+    h2, lit2, rgb2 = O.brute_shade_rays(plain, rays[:512], threads=threads)
+    assert h2.tobytes() == hits[:512].tobytes() and np.array_equal(lit2, lit[:512]) and np.array_equal(rgb2, rgb[:512])
+    mask = (lit.astype(np.uint8) << np.arange(lit.shape[1], dtype=np.uint8)).sum(axis=1).astype(np.uint8)
+    out = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(out, px=px, py=py, id=hits["id"].astype(np.int32), dist=hits["dist"], lit_mask=mask, rgb_linear=rgb,
+                        res=np.array(res, dtype=np.int32), pixel_seed=np.array(seed, dtype=np.int64),
+                        n_prims=np.array(len(prims), dtype=np.int64), n_lights=np.array(len(lights), dtype=np.int64))
+    print("%s: %d pixels, %d hits, %d lit of %d shadow rays, %.0f s on %d threads -> %s (%d bytes)"
+          % (name, n_pixels, int((hits["hit"] == 1).sum()), int(lit.sum()), int((hits["hit"] == 1).sum()) * len(lights), dt, threads,
+             out, os.path.getsize(out)))
+
+
+def instanced(n_pixels, seed, threads):
+    O = bind.Oracle()
+    prims, inst, lights, camd = S.instanced_field(mirror=True)
+    W, H = camd["res"]
+    cam = bind.camera_from_dict(O, camd)
+    px, py = sample_pixels(seed, W, H, n_pixels)
+    rays = O.pixel_rays(cam, np.stack([px + 0.5, py + 0.5], axis=1))
+    sc = O.instanced_scene(prims, inst, lights)
+    t0 = time.time()
+    hits = O.trace_rays(sc, rays, threads=threads)
+    rgb = O.trace_rays_rgb(sc, rays, max_scatters=2, threads=threads)
+    rgb0 = O.trace_rays_rgb(sc, rays, max_scatters=0, threads=threads)
+    dt = time.time() - t0
+    out = os.path.join(GOLDEN, "config5_sample.npz")
+    np.savez_compressed(out, px=px, py=py, id=hits["id"].astype(np.int32), dist=hits["dist"], rgb_linear_2_bounces=rgb,
+                        rgb_linear_0_bounces=rgb0, res=np.array((W, H), dtype=np.int32), pixel_seed=np.array(seed, dtype=np.int64),
+                        n_instances=np.array(len(inst), dtype=np.int64), n_mesh_prims=np.array(len(prims), dtype=np.int64))
+    print("config5: %d pixels, %d hits, %.0f s -> %s (%d bytes)" % (n_pixels, int((hits["hit"] == 1).sum()), dt, out, os.path.getsize(out)))
+
+
+def ref_bvh(threads):
+    R = bind.Ref()
+    O = bind.Oracle()
+    prims = S.mixed_field(n_side=1000, seed=0x100000, planes_as_triangles=False)
+    W, H = 3840, 2160
+    cam = bind.camera_from_dict(O, S.mixed_field_camera(res=(W, H)))
+    h = R.prims_create(prims)
+    t0 = time.time()
+    ids = np.empty((H, W), dtype=np.int32)
+    rows = 120
+    for y0 in range(0, H, rows):
+        yy, xx = np.mgrid[y0:y0 + rows, 0:W]
+        rays = O.pixel_rays(cam, np.stack([xx.ravel() + 0.5, yy.ravel() + 0.5], axis=1))
+        ids[y0:y0 + rows] = R.prims_trace_bvh(h, rays, threads=threads)[0].reshape(rows, W)
+        print("rows %d..%d, %.0f s" % (y0, y0 + rows, time.time() - t0), flush=True)
+    # the reference's own brute-force loop on a few of the same rays (its hierarchy is only right for rays that start
+    # outside every box, which these do)
+    rng = np.random.default_rng(5)
+    sx, sy = rng.integers(0, W, 64), rng.integers(H // 3, H, 64)
+    rays = O.pixel_rays(cam, np.stack([sx + 0.5, sy + 0.5], axis=1))
+    bid, _ = R.prims_trace_brute(h, rays, threads=threads)
+    assert np.array_equal(bid, ids[sy, sx])
+    R.prims_free(h)
+    out = os.path.join(GOLDEN, "config3_ref_bvh_ids.npz")
+    np.savez_compressed(out, ids=ids, n_prims=np.array(len(prims), dtype=np.int64))
+    print("config3_ref_bvh: %d hits, %.0f s -> %s (%d bytes)" % (int((ids >= 0).sum()), time.time() - t0, out, os.path.getsize(out)))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["config3", "config4", "config5", "config3_ref_bvh"])
+    ap.add_argument("--pixels", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=6)
+    a = ap.parse_args()
+    if a.what == "config3":
+        mixed("config3_sample", (3840, 2160), a.pixels or 65536, 0xC3, a.threads)
+    elif a.what == "config4":
+        mixed("config4_sample", (7680, 4320), a.pixels or 16384, 0xC4, a.threads)
+    elif a.what == "config5":
+        instanced(a.pixels or 65536, 0xC5, a.threads)
+    else:
+        ref_bvh(a.threads)

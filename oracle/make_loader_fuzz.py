@@ -93,6 +93,11 @@ def documents():
     add("no_lights", d, indent=1)
     d = base(); d["LIGHT"]["POINT"]["92"] = {"location": v(0, 0, 9)}; d["LIGHT"]["POINT"]["93"] = {"radiant_intensity": 99.0}
     add("light_defaults_and_light_without_location", d, indent=1)
+    # a light id given twice: the reference keeps lights in a map keyed by the id text, the later block replaces the earlier
+    text = json.dumps(base(), indent=1)
+    cut = text.rindex("}", 0, text.rindex("}", 0, text.rindex("}")))          # the brace that closes POINT
+    text = text[:cut] + ', "90": {"location": {"x": -2.0, "y": -6.0, "z": 3.0}, "radiant_intensity": 21.0}\n' + text[cut:]
+    add("light_id_given_twice", text)
     d = base(); d["CAMERA"]["PERSP"]["8"] = dict(CAM, location=v(6, -6, 5), direction=v(-0.6, 0.6, -0.45), up=v(0.1, 0.2, 0.97))
     d["CAMERA"]["PERSP"]["9"] = {"location": v(0, 0, 12), "direction": v(0, 0, -1)}                          # straight down, all defaults
     add("several_cameras_up_vector_and_defaults", d, cams=("7", "8", "9", "10"), indent=1)

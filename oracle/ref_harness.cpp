@@ -24,6 +24,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "raytracer.h"
@@ -198,6 +199,74 @@ int ref_camera_rays(const char* json_path, const char* camera_id, const double* 
         r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
     }
     return 1;
+}
+
+// A scene built through the reference's public constructors (no JSON: its loader is quadratic in the number of
+// objects), in the reference's id order - cubes, planes, cylinders, spheres (raytracer.cpp:20-27); the caller passes
+// the primitives already in that order.  kind / params as ref_intersect_prim (12 doubles per primitive).
+struct RefPrims {
+    std::vector<std::unique_ptr<Mesh>> owned;
+    std::vector<const Mesh*> ptrs;
+    std::unordered_map<const Mesh*, int> index;
+    std::vector<std::unique_ptr<BoundingBox>> node_store;
+    const Mesh* root = nullptr;
+    bool built = false;
+};
+
+void* ref_prims_create(const int* kinds, const double* params12, long n) {
+    auto* s = new RefPrims();
+    s->owned.reserve(n); s->ptrs.reserve(n);
+    for (long i = 0; i < n; ++i) {
+        const double* q = params12 + i * 12;
+        Mesh* m = nullptr;
+        switch (kinds[i]) {
+            case 0: m = new Cube(Float3{q[0],q[1],q[2]}, EulerAngles{q[3],q[4],q[5]}, Float3{q[6],q[7],q[8]}); break;
+            case 1: m = new Plane(std::vector<Float3>{ {q[0],q[1],q[2]}, {q[3],q[4],q[5]}, {q[6],q[7],q[8]}, {q[9],q[10],q[11]} }); break;
+            case 2: m = new Cylinder(Float3{q[0],q[1],q[2]}, EulerAngles{q[3],q[4],q[5]}, Float3{q[6],q[7],q[8]}); break;
+            case 3: m = new Sphere(Float3{q[0],q[1],q[2]}, Float3{q[3],q[4],q[5]}); break;
+            default: delete s; return nullptr;
+        }
+        s->owned.emplace_back(m);
+        s->ptrs.push_back(m);
+        s->index[m] = static_cast<int>(i);
+    }
+    return s;
+}
+
+void ref_prims_free(void* h) { delete static_cast<RefPrims*>(h); }
+
+// get_BVH_tree + accelerated_one_pass_intersection (raytracer.cpp:454-551) for n rays: ids and distances.  The
+// traversal only reads the tree, so rays are spread over OpenMP threads.
+void ref_prims_trace_bvh(void* h, const double* rays6, long n, int* ids, double* dist, int threads) {
+    RefPrims* s = static_cast<RefPrims*>(h);
+    if (!s->built) { s->root = get_BVH_tree(s->ptrs, s->node_store); s->built = true; }
+    #pragma omp parallel for schedule(dynamic, 256) num_threads(threads > 0 ? threads : 1)
+    for (long i = 0; i < n; ++i) {
+        Hit hit;
+        const bool ok = s->root && accelerated_one_pass_intersection(s->root, make_ray(rays6 + i*6), hit);
+        ids[i] = -1; dist[i] = std::numeric_limits<double>::infinity();
+        if (ok && hit.hasMesh()) { ids[i] = s->index.at(hit.getMesh()); dist[i] = hit.getDistanceAlongRay(); }
+    }
+}
+
+// The loop of RayTracer::one_pass_intersection (raytracer.cpp:143-157) over the same primitives: every primitive's
+// intersect, strict '<' on the distance, first in order wins.
+void ref_prims_trace_brute(void* h, const double* rays6, long n, int* ids, double* dist, int threads) {
+    RefPrims* s = static_cast<RefPrims*>(h);
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (long i = 0; i < n; ++i) {
+        const Ray ray = make_ray(rays6 + i*6);
+        double best = std::numeric_limits<double>::infinity();
+        int best_id = -1;
+        for (size_t k = 0; k < s->ptrs.size(); ++k) {
+            Hit tmp;
+            if (s->ptrs[k]->intersect(ray, tmp) && tmp.hasDistanceAlongRay()) {
+                const double d = tmp.getDistanceAlongRay();
+                if (d < best) { best = d; best_id = static_cast<int>(k); }
+            }
+        }
+        ids[i] = best_id; dist[i] = best;
+    }
 }
 
 // The reference's own timing functions (s2899221/Code/raytracer.cpp:553,567), for the "reference" CPU baseline.

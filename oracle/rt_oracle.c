@@ -5,6 +5,7 @@
 #include "rt_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -428,6 +429,7 @@ int rto_closest_hit(const rto_scene* sc, const double o[3], const double d[3], r
     int any = 0;
     for (int64_t i = 0; i < sc->n_prims; ++i) {
         rto_hit h;
+        if (sc->prim_bounds && !may_touch(o, d, sc->prim_bounds + 6*i)) continue;
         if (rto_intersect(&sc->prims[i], o, d, &h)) {
             if (h.dist < best.dist) { best = h; best.id = (int32_t)i; best.prim = (int32_t)i; any = 1; }
         }
@@ -501,6 +503,17 @@ static int brute_occluded(const void* ctx, const double o[3], const double d[3],
     return 0;
 }
 
+/* Origin of the shadow ray from p (unit normal n) towards a light in unit direction ldir, nudged 1e-4 along the normal
+ * on the light's side; returns the light's distance (s2899221/Code/raytracer.cpp:217-228). */
+static double shadow_origin(const double p[3], const double n[3], const double ldir[3], double dist2, double so[3]) {
+    const double light_dist = sqrt(dist2);
+    const double eps = 1e-4;
+    const double ndl = n[0]*ldir[0] + n[1]*ldir[1] + n[2]*ldir[2];
+    const double s = (ndl >= 0.0) ? 1.0 : -1.0;
+    so[0] = p[0] + s * n[0] * eps; so[1] = p[1] + s * n[1] * eps; so[2] = p[2] + s * n[2] * eps;
+    return light_dist;
+}
+
 static void shade_with(const rto_scene* sc, const rto_hit* hit, const double ray_o[3], uint8_t rgb[3],
                        occluded_fn occ, const void* occ_ctx, int64_t* shadow_rays) {
     rgb[0] = rgb[1] = rgb[2] = 0;
@@ -524,11 +537,8 @@ static void shade_with(const rto_scene* sc, const rto_hit* hit, const double ray
         const double dist2 = (1e-12 < len2) ? len2 : 1e-12;
         double ldir[3]; normalize3(lx, ly, lz, ldir);
         {
-            const double light_dist = sqrt(dist2);
-            const double eps = 1e-4;
-            const double ndl = n[0]*ldir[0] + n[1]*ldir[1] + n[2]*ldir[2];
-            const double s = (ndl >= 0.0) ? 1.0 : -1.0;
-            const double so[3] = { p[0] + s * n[0] * eps, p[1] + s * n[1] * eps, p[2] + s * n[2] * eps };
+            double so[3];
+            const double light_dist = shadow_origin(p, n, ldir, dist2, so);
             if (shadow_rays) ++*shadow_rays;
             if (occ(occ_ctx, so, ldir, light_dist)) continue;
         }
@@ -705,6 +715,118 @@ void rto_shade_rays(const rto_scene* sc, const double* rays6, int64_t n, uint8_t
         rto_hit h; rto_closest_hit(sc, rays6 + i*6, rays6 + i*6 + 3, &h);
         rto_shade(sc, &h, rays6 + i*6, rgb + i*3);
     }
+}
+
+void rto_trace_rays_rgb(const rto_scene* sc, const double* rays6, int64_t n, int max_scatters, double min_scatter_intensity,
+                        uint8_t* rgb, int threads) {
+    const int nt = pick_threads(threads); (void)nt;
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+    for (int64_t i = 0; i < n; ++i)
+        rto_trace(sc, rays6 + i*6, rays6 + i*6 + 3, 0, max_scatters, min_scatter_intensity, rgb + i*3);
+}
+
+void rto_hit_bounds(const rto_prim* prims, int64_t n, double* out6) {
+    for (int64_t i = 0; i < n; ++i) {
+        const rto_prim* p = &prims[i];
+        double* b = out6 + 6*i;
+        const double* q = p->q;
+        int bounded = 1;
+        if (p->kind == RTO_PLANE) {
+            /* the points Plane::intersect can return: P0 + u e1 + v e2 over the unit square (mesh.cpp:799-804, 878-886) */
+            const double c[4][3] = { { q[0], q[1], q[2] }, { q[3], q[4], q[5] }, { q[9], q[10], q[11] },
+                                     { q[3] + q[9] - q[0], q[4] + q[10] - q[1], q[5] + q[11] - q[2] } };
+            for (int k = 0; k < 3; ++k) {
+                b[k] = c[0][k]; b[3 + k] = c[0][k];
+                for (int j = 1; j < 4; ++j) { if (c[j][k] < b[k]) b[k] = c[j][k]; if (c[j][k] > b[3 + k]) b[3 + k] = c[j][k]; }
+            }
+        } else {
+            rto_aabb(p, b, b + 3);
+            if (p->kind != RTO_TRIANGLE) {
+                const double* s = (p->kind == RTO_SPHERE) ? q + 3 : q + 6;
+                for (int k = 0; k < 3; ++k) if (s[k] == 0.0 || !isfinite(s[k])) bounded = 0;
+            }
+        }
+        for (int k = 0; k < 6; ++k) if (!isfinite(b[k])) bounded = 0;
+        if (!bounded) { b[0] = b[1] = b[2] = -RTO_INF; b[3] = b[4] = b[5] = RTO_INF; }
+    }
+}
+
+/* rto_closest_hit for a batch, rays and primitives in blocks (64 rays x 512 primitives stay in cache); per ray the
+ * primitives still come in ascending id order, so strict '<' resolves ties as one_pass_intersection does
+ * (s2899221/Code/raytracer.cpp:143-157). */
+static void closest_hits_blocked(const rto_scene* sc, const double* rays6, int64_t n, rto_hit* out, int nt) {
+    if (sc->instanced) {
+        #pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+        for (int64_t i = 0; i < n; ++i) rto_closest_hit(sc, rays6 + i*6, rays6 + i*6 + 3, &out[i]);
+        return;
+    }
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+    for (int64_t b0 = 0; b0 < n; b0 += 64) {
+        const int64_t b1 = (b0 + 64 < n) ? b0 + 64 : n;
+        for (int64_t i = b0; i < b1; ++i) hit_clear(&out[i]);
+        for (int64_t c0 = 0; c0 < sc->n_prims; c0 += 512) {
+            const int64_t c1 = (c0 + 512 < sc->n_prims) ? c0 + 512 : sc->n_prims;
+            for (int64_t i = b0; i < b1; ++i) {
+                const double* o = rays6 + i*6; const double* d = o + 3;
+                for (int64_t j = c0; j < c1; ++j) {
+                    if (sc->prim_bounds && !may_touch(o, d, sc->prim_bounds + 6*j)) continue;
+                    rto_hit h;
+                    if (rto_intersect(&sc->prims[j], o, d, &h) && h.dist < out[i].dist) {
+                        out[i] = h; out[i].id = (int32_t)j; out[i].prim = (int32_t)j;
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef struct { const uint8_t* lit; int next; } verdict_list;
+static int listed_occluded(const void* ctx, const double o[3], const double d[3], double light_dist) {
+    verdict_list* v = (verdict_list*)ctx; (void)o; (void)d; (void)light_dist;
+    return v->lit[v->next++] ? 0 : 1;
+}
+
+void rto_brute_shade_rays(const rto_scene* sc, const double* rays6, int64_t n, rto_hit* hits, uint8_t* lit,
+                          uint8_t* rgb, int threads) {
+    const int nt = pick_threads(threads);
+    const int64_t L = sc->n_lights;
+    closest_hits_blocked(sc, rays6, n, hits, nt);
+    if (L <= 0) { memset(rgb, 0, (size_t)n * 3u); return; }
+    /* the shadow rays of shade() for every hit and light, as shade_with builds them */
+    int64_t n_hit = 0;
+    for (int64_t i = 0; i < n; ++i) n_hit += hits[i].hit ? 1 : 0;
+    double* srays = (double*)malloc((size_t)(n_hit * L > 0 ? n_hit * L : 1) * 6u * sizeof(double));
+    double* sdist = (double*)malloc((size_t)(n_hit * L > 0 ? n_hit * L : 1) * sizeof(double));
+    rto_hit* shits = (rto_hit*)malloc((size_t)(n_hit * L > 0 ? n_hit * L : 1) * sizeof(rto_hit));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!hits[i].hit) continue;
+        double nn[3]; normalize3(hits[i].n[0], hits[i].n[1], hits[i].n[2], nn);
+        const double* p = hits[i].p;
+        for (int64_t li = 0; li < L; ++li, ++k) {
+            const rto_light* Lt = &sc->lights[li];
+            const double lx = Lt->pos[0] - p[0], ly = Lt->pos[1] - p[1], lz = Lt->pos[2] - p[2];
+            const double len2 = lx*lx + ly*ly + lz*lz;
+            const double dist2 = (1e-12 < len2) ? len2 : 1e-12;
+            double ldir[3]; normalize3(lx, ly, lz, ldir);
+            sdist[k] = shadow_origin(p, nn, ldir, dist2, srays + 6*k);
+            srays[6*k + 3] = ldir[0]; srays[6*k + 4] = ldir[1]; srays[6*k + 5] = ldir[2];
+        }
+    }
+    closest_hits_blocked(sc, srays, n_hit * L, shits, nt);
+    k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t li = 0; li < L; ++li) lit[i*L + li] = 0;
+        if (hits[i].hit)
+            for (int64_t li = 0; li < L; ++li, ++k) {
+                const double t = shits[k].dist;
+                const int blocked = shits[k].hit && t > 1e-4 && t < sdist[k] - 1e-4;      /* raytracer.cpp:230-235 */
+                lit[i*L + li] = blocked ? 0 : 1;
+            }
+        verdict_list v = { lit + i*L, 0 };
+        shade_with(sc, &hits[i], rays6 + i*6, rgb + i*3, listed_occluded, &v, 0);
+    }
+    free(srays); free(sdist); free(shits);
 }
 
 /* Pixel centres (x + 0.5, y + 0.5), row-major, y down: s2899221/Code/raytracer.cpp:131-134. */

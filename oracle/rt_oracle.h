@@ -86,6 +86,11 @@ typedef struct rto_scene {
     /* optional, 6 doubles per instance: bounds of its mesh in the mesh's frame (min xyz, max xyz).  Only used to skip
      * instances a ray cannot touch (a padded FP64 slab test); results are the same with or without it. */
     const double* inst_bounds;
+    /* optional, 6 doubles per primitive (rto_hit_bounds): a box that holds every point the primitive's intersector can
+     * return.  Only used by the brute-force loop to pass over primitives a ray cannot touch (the same padded FP64 slab
+     * test); every primitive the ray can touch is still tested, in ascending id order, so results are the same with
+     * or without it (tests/test_oracle_golden.py, tests/test_oracle_vs_ref.py). */
+    const double* prim_bounds;
 } rto_scene;
 
 /* 32-byte BVH node shared with the product's flattened layout: internal nodes have count == 0 and
@@ -115,6 +120,22 @@ void rto_render(const rto_scene* sc, const rto_camera* cam, int x0, int y0, int 
                 int max_scatters, double min_scatter_intensity, uint8_t* rgb,
                 int64_t* n_hits, int64_t* shadow_rays, int threads);
 void rto_gamma_lut(uint8_t lut[256]);
+/* rto_trace (trace_ray_recursive, raytracer.cpp:281-371) per ray: linear 8-bit colour, 3 bytes per ray. */
+void rto_trace_rays_rgb(const rto_scene* sc, const double* rays6, int64_t n, int max_scatters, double min_scatter_intensity,
+                        uint8_t* rgb, int threads);
+
+/* Box holding every point each primitive's intersector can return (min xyz, max xyz per primitive): the reference's
+ * compute_aabb for cube / cylinder / ellipsoid, the parallelogram of corners 0, 1, 3 for a plane (its intersector
+ * ignores corner 2, mesh.cpp:799-804), the corners of a triangle; a primitive with a zero or non-finite scale is not
+ * bounded by its corner box and gets an infinite one. */
+void rto_hit_bounds(const rto_prim* prims, int64_t n, double* out6);
+/* Brute force at sizes where one ray costs a million primitive tests: for each ray the closest hit of
+ * rto_closest_hit (hits), then RayTracer::shade's shadow ray towards every light from every hit, each resolved by
+ * the same loop over ALL primitives (lit[i * n_lights + l] = 1 when light l reaches hit i, 0 when it is blocked or ray
+ * i missed), and the linear 8-bit colour those verdicts give (rgb, 3 bytes per ray; no gamma).  Rays and primitives are
+ * visited in cache-sized blocks; per ray the primitives are still met in ascending id order with strict '<'. */
+void rto_brute_shade_rays(const rto_scene* sc, const double* rays6, int64_t n, rto_hit* hits, uint8_t* lit,
+                          uint8_t* rgb, int threads);
 
 /* The product's flattened BVH, as rt_scene_get_bvh / rt_scene_get_info hand it out: slot_prim maps
  * primitive slots to ids, the first n_slots in BVH leaf order followed by n_loose unbounded primitives

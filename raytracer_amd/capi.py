@@ -259,6 +259,8 @@ class Scene:
             assert a.ndim == 3 and a.shape[2] == 3
             table[k] = Texture(a.shape[1], a.shape[0], a.ctypes.data)
         pt = np.ascontiguousarray(prim_texture, dtype=np.int32)
+        if len(arrs) and len(pt) != int(self.info().n_prims):      # the library reads one entry per primitive
+            raise ValueError("prim_texture needs one entry per primitive (%d), got %d" % (int(self.info().n_prims), len(pt)))
         _check(lib().rt_scene_set_textures(self.h, table, len(arrs), _ptr(pt)))
 
     def texture(self, prim_id):

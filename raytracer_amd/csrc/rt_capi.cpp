@@ -410,16 +410,31 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     return RT_OK;
 }
 
+namespace {
+// The frame working set, the queue heads and the counters are shared by whatever stream the context launches on: work
+// queued on the new stream must start after what is still pending on the old one.
+int switch_stream(rt_ctx* ctx, hipStream_t to) {
+    if (to == ctx->stream) return RT_OK;
+    if (int rc = use(ctx)) return rc;
+    hipEvent_t done = nullptr;
+    RT_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(done, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, done, 0);
+    (void)hipEventDestroy(done);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("stream switch: ") + hipGetErrorString(e));
+    ctx->stream = to;
+    return RT_OK;
+}
+} // namespace
+
 int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
-    return RT_OK;
+    return switch_stream(ctx, static_cast<hipStream_t>(hip_stream));
 }
 
 int rt_ctx_use_own_stream(rt_ctx* ctx) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
-    ctx->stream = ctx->own_stream;
-    return RT_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 int rt_ctx_synchronize(rt_ctx* ctx) {

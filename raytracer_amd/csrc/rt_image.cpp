@@ -2,6 +2,7 @@
 #include <cctype>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 
 #include "rt_scene.h"
@@ -54,9 +55,14 @@ bool rt_load_ppm(const char* path, int32_t& width, int32_t& height, int32_t& max
     if (w <= 0 || h <= 0 || mv <= 0) { err = "Invalid PPM header values"; return false; }
     if (mv > 255) { err = "Unsupported PPM max value (>255 not supported)"; return false; }
     const size_t count = static_cast<size_t>(w) * static_cast<size_t>(h) * 3u;
+    // the payload must be there before anything of that size is allocated (a P3 sample takes at least two bytes, the
+    // last one at least one): a few header bytes must not be able to ask for gigabytes
+    if (magic == "P6" ? buf.size() - r.pos < count : (buf.size() - r.pos + 1) / 2 < count) {
+        err = magic == "P6" ? "Unexpected EOF while reading binary PPM data" : "Unexpected EOF reading P3 data";
+        return false;
+    }
     rgb.resize(count);
     if (magic == "P6") {
-        if (buf.size() - r.pos < count) { err = "Unexpected EOF while reading binary PPM data"; return false; }
         std::memcpy(rgb.data(), buf.data() + r.pos, count);
     } else {
         for (size_t i = 0; i < count; i += 3) {
@@ -87,11 +93,14 @@ void rt_scene_attach_textures(rt_scene* s, const std::vector<std::string>& tex_p
         if (it == seen.end()) {
             int32_t w = 0, h = 0, mv = 0; std::vector<uint8_t> rgb; std::string err;
             int32_t index = -1;
-            if (rt_load_ppm(tex_paths[i].c_str(), w, h, mv, rgb, err)) {
-                index = static_cast<int32_t>(s->tex_table.size());
-                s->tex_table.push_back(rt_tex_rec{ s->texels.size(), w, h });
-                s->texels.insert(s->texels.end(), rgb.begin(), rgb.end());
-            }
+            try {       // whatever goes wrong with one texture, the primitive keeps its solid colour (mesh.cpp:105-110)
+                if (rt_load_ppm(tex_paths[i].c_str(), w, h, mv, rgb, err)) {
+                    const size_t before = s->texels.size();
+                    s->texels.insert(s->texels.end(), rgb.begin(), rgb.end());
+                    s->tex_table.push_back(rt_tex_rec{ before, w, h });
+                    index = static_cast<int32_t>(s->tex_table.size()) - 1;
+                }
+            } catch (const std::exception&) { index = -1; }
             it = seen.emplace(tex_paths[i], index).first;
         }
         s->prim_tex[i] = it->second;

@@ -103,9 +103,9 @@ struct Parser {
             const double v = std::strtod(tok.c_str(), &e);
             if (e == tok.c_str()) ok = fail("malformed number");
             n.type = Node::Number; n.number = v; n.unsigned_integer_text = digits_only;
-        } else if (!std::strncmp(p, "true", 4) && end - p >= 4)  { n.type = Node::Bool; n.number = 1; p += 4; }
-        else if (!std::strncmp(p, "false", 5) && end - p >= 5)   { n.type = Node::Bool; p += 5; }
-        else if (!std::strncmp(p, "null", 4) && end - p >= 4)    { n.type = Node::Null; p += 4; }
+        } else if (end - p >= 4 && !std::memcmp(p, "true", 4))  { n.type = Node::Bool; n.number = 1; p += 4; }
+        else if (end - p >= 5 && !std::memcmp(p, "false", 5))   { n.type = Node::Bool; p += 5; }
+        else if (end - p >= 4 && !std::memcmp(p, "null", 4))    { n.type = Node::Null; p += 4; }
         else ok = fail("unexpected character");
         --depth;
         return ok;
@@ -265,6 +265,7 @@ int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>&
     }
 
     prims.clear(); lights.clear(); cameras.clear(); tex_paths.clear();
+    std::vector<std::string> light_ids;
     if (const Node* mesh = find_block(root, "MESH")) {
         // primitive-id order of rebuild_mesh_ptrs: cubes, planes, cylinders, spheres (raytracer.cpp:20-27)
         if (const Node* c = find_block(*mesh, "Cube"))
@@ -322,10 +323,14 @@ int rt_parse_scene_text(const char* text, size_t len, std::vector<rt_prim_desc>&
             });
     if (const Node* li = find_block(root, "LIGHT"))
         if (const Node* pt = find_block(*li, "POINT"))
-            for_each_object(*pt, [&](const std::string&, const Node& o) {
+            for_each_object(*pt, [&](const std::string& id, const Node& o) {
                 rt_light L; L.intensity = 1.0;
                 if (!get_vec3(o, "location", L.pos)) return;
                 get_number(o, "radiant_intensity", L.intensity);
+                // the reference keeps lights in a map keyed by the id text (raytracer.cpp:103): a repeated id replaces
+                // the earlier light
+                for (size_t k = 0; k < light_ids.size(); ++k) if (light_ids[k] == id) { lights[k] = L; return; }
+                light_ids.push_back(id);
                 lights.push_back(L);
             });
     return RT_OK;

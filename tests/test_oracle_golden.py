@@ -178,3 +178,24 @@ def test_textured_scene(oracle, tmp_path):
     # the textures matter: without them the frame differs
     plain, _, _ = oracle.render(oracle.scene(prims, lights), cam, max_scatters=0)
     assert not np.array_equal(plain, g["render0"])
+
+
+@pytest.mark.parametrize("seed,kinds", [(31, (0, 1, 2, 3, 4)), (32, (0, 3)), (33, (1, 4))])
+def test_blocked_brute_force_equals_the_plain_loop(oracle, seed, kinds):
+    """rto_brute_shade_rays - the loop that makes the fixtures at a million primitives - against rto_trace_rays /
+    rto_shade_rays (both pinned on the reference's fixtures above): hits, verdict-derived colours, with and without the
+    per-primitive boxes, with degenerate (zero-scale) primitives in the scene."""
+    from raytracer_amd import scenes as S
+    prims, lights, camd = S.random_scene(700, seed, kinds=kinds, lights=3)
+    prims["q"][5, 6:9] = 0.0                      # a cube / plane record with zeroed tail: unbounded or degenerate
+    cam = bind.camera_from_dict(oracle, dict(camd, res=(64, 48)))
+    ys, xs = np.mgrid[0:48, 0:64]
+    rays = oracle.pixel_rays(cam, np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], axis=1))
+    sc = oracle.scene(prims, lights)
+    want, want_lin = oracle.trace_rays(sc, rays), oracle.shade_rays(sc, rays)
+    for scb in (sc, oracle.with_prim_bounds(oracle.scene(prims, lights))):
+        hits, lit, lin = oracle.brute_shade_rays(scb, rays, threads=4)
+        assert hits.tobytes() == want.tobytes()
+        assert np.array_equal(lin, want_lin)
+        assert lit.shape == (len(rays), 3) and not lit[hits["hit"] == 0].any()
+        assert oracle.trace_rays(scb, rays).tobytes() == want.tobytes()

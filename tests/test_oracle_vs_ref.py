@@ -38,6 +38,13 @@ def test_random_scene_live(oracle, ref, seed, n, nl):
         for f in ("dist", "p", "n", "r", "u", "v"):
             assert np.array_equal(bits(a[f]), bits(b[f])), f
         assert np.array_equal(ref.shade_rays(h, rays), oracle.shade_rays(sc, rays))
+        # the blocked brute-force loop that makes the fixtures at a million primitives, with and without the
+        # per-primitive boxes that let it pass over primitives: the reference's hits and colours, bit for bit
+        for scb in (oracle.scene(prims, lights), oracle.with_prim_bounds(oracle.scene(prims, lights))):
+            hb, lit, lin = oracle.brute_shade_rays(scb, rays)
+            assert np.array_equal(a["id"], hb["id"]) and np.array_equal(bits(a["dist"]), bits(hb["dist"]))
+            assert np.array_equal(ref.shade_rays(h, rays), lin)
+            assert not lit[hb["hit"] == 0].any()
         for ms in (0, 3):
             out = os.path.join(td, "o.ppm")
             assert ref.render_ppm(h, "3", out, 1, ms, 0.0)
