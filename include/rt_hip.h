@@ -235,8 +235,8 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
 /* rt_render_rect with max_scatters = 0 for callers that cannot allocate device memory: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The frame working
  * set (80 bytes per pixel: hit points, normals, light sums, record slots, shadow verdicts) and the work-queue heads
- * live in a fixed workspace compiled into the library - a __device__ array of RT_STATIC_MAX_PIXELS * 80 + 4096 bytes
- * (20 MiB), of which every GPU the library runs on holds its own copy until the process ends - so the call makes no
+ * live in a fixed workspace compiled into the library - a __device__ array of 84 bytes per pixel of the limit below
+ * (21 MiB), of which every GPU the library runs on holds its own copy until the process ends - so the call makes no
  * hipMalloc / hipFree and calls no allocating routine.  Limit: rect.w * rect.h <= RT_STATIC_MAX_PIXELS (262144, e.g.
  * 512 x 512); larger rectangles return RT_ERR_LIMIT - render them in pieces.  Launch timing (rt_ctx_set_timing)
  * must be off (RT_ERR_INVALID otherwise: it creates events).  All calls on one GPU share that GPU's workspace: calls
@@ -269,6 +269,14 @@ int rt_timing_read(rt_ctx* ctx, rt_timing* out);
 /* When on, trace / render launches use the instrumented kernels that also count BVH node and primitive
  * record fetches per ray class (slower; for roofline accounting and tests). */
 int rt_ctx_set_counting(rt_ctx* ctx, int on);
+
+/* Entry search (on by default; scenes walked through wide nodes, not instanced ones): before a closest-hit or shadow
+ * launch of the frame pipeline one lane per 8x8-pixel tile follows the tile's beam of rays down from the root for as long
+ * as the beam can touch only one child of a node, and the tile's rays start their walks there.  A subtree is passed over
+ * only when no ray of the beam can touch its box, so results are identical with it on or off; only the node counters
+ * differ (the counting kernels then include the boxes the search itself fetched).  The reference has no counterpart
+ * (its traversal starts every ray at the root, raytracer.cpp:501-512). */
+int rt_ctx_set_entry_search(rt_ctx* ctx, int on);
 
 /* Convenience for host-memory callers (the C++ host mirror): whole-frame render / trace into host buffers.
  * These allocate device scratch inside the context and synchronise. */

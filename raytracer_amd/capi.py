@@ -119,6 +119,7 @@ SYMBOLS = [
     ("rt_counters_read", C.c_int, [_VP, C.POINTER(Counters)]),
     ("rt_ctx_set_counting", C.c_int, [_VP, C.c_int]),
     ("rt_ctx_set_timing", C.c_int, [_VP, C.c_int]),
+    ("rt_ctx_set_entry_search", C.c_int, [_VP, C.c_int]),
     ("rt_timing_read", C.c_int, [_VP, C.POINTER(Timing)]),
     ("rt_render_frame_host", C.c_int, [_VP, C.POINTER(Camera), C.c_int, _D, _VP, _VP]),
     ("rt_trace_primary_host", C.c_int, [_VP, C.POINTER(Camera), _VP, _VP]),
@@ -406,6 +407,10 @@ class Context:
 
     def set_counting(self, on):
         _check(lib().rt_ctx_set_counting(self.h, 1 if on else 0))
+
+    def set_entry_search(self, on):
+        """Start each tile's walks at the deepest node its beam of rays must pass through (default on)."""
+        _check(lib().rt_ctx_set_entry_search(self.h, 1 if on else 0))
 
     def set_timing(self, on):
         _check(lib().rt_ctx_set_timing(self.h, 1 if on else 0))

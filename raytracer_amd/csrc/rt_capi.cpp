@@ -62,6 +62,7 @@ struct rt_ctx {
     size_t static_scratch_bytes = 0;
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
     int refill_min = RT_REFILL_MIN;
+    bool entry_search = true;              // start a tile's walks below the root where its beam allows (rt_ctx_set_entry_search)
     // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -374,6 +375,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
             int per_cu = 16;                                   // 4 waves per SIMD at <= 128 VGPRs
             if (const char* env = std::getenv("RT_WAVES_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 32) per_cu = v; }
             c->max_waves = static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu;
+            if (const char* env = std::getenv("RT_ENTRY_SEARCH")) c->entry_search = std::atoi(env) != 0;
             if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_min = v; }
         }
     }
@@ -469,6 +471,11 @@ int rt_timing_read(rt_ctx* ctx, rt_timing* out) {
 int rt_ctx_set_counting(rt_ctx* ctx, int on) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     ctx->counting = on != 0; return RT_OK;
+}
+
+int rt_ctx_set_entry_search(rt_ctx* ctx, int on) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->entry_search = on != 0; return RT_OK;
 }
 
 int rt_counters_reset(rt_ctx* ctx) {
@@ -680,9 +687,19 @@ uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
 // verdict byte per slot and light of a batch.
 constexpr size_t kFramePlanes = 7;
 size_t frame_bytes(size_t n, uint32_t n_batch) {
-    return n * (kFramePlanes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + n_batch) + 256;
+    (void)n_batch;
+    return n * (kFramePlanes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + RT_LIGHT_BATCH) + 256;
+}
+// Per-tile planes of the entry search: 4 + 4 * RT_LIGHT_BATCH bytes of references and 24 of box per tile.
+static_assert(RT_TILE_BYTES >= sizeof(uint32_t) * (1 + RT_LIGHT_BATCH) + 6 * sizeof(float), "tile planes");
+size_t tile_bytes(size_t n_tiles) { return n_tiles * RT_TILE_BYTES + 256; }
+void carve_tiles(void* base, size_t n_tiles, FrameBufs& fb) {
+    fb.entry_p = static_cast<uint32_t*>(base);
+    fb.entry_s = fb.entry_p + n_tiles;
+    fb.tile_box = reinterpret_cast<float*>(fb.entry_s + n_tiles * RT_LIGHT_BATCH);
 }
 void carve_frame(void* base, size_t n, bool textures, FrameBufs& fb) {
+    fb.entry_p = nullptr; fb.entry_s = nullptr; fb.tile_box = nullptr;
     double* d = static_cast<double*>(base);
     fb.px = d; fb.py = d + n; fb.pz = d + 2*n; fb.nx = d + 3*n; fb.ny = d + 4*n; fb.nz = d + 5*n;
     fb.lighting = d + 6*n;
@@ -695,10 +712,14 @@ void carve_frame(void* base, size_t n, bool textures, FrameBufs& fb) {
 }
 
 // The same out of the context's grow-only scratch (allocated on first use of a size).
-int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, FrameBufs& fb) {
+bool wants_entry_search(const rt_ctx* ctx) { return ctx->entry_search && ctx->sc.nodes4 && !ctx->sc.inst; }
+int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, size_t n_tiles, FrameBufs& fb) {
     void* base = nullptr;
-    if (int rc = ctx->need(3, frame_bytes(n, n_batch), &base)) return rc;
+    const size_t fbytes = (frame_bytes(n, n_batch) + 255u) & ~static_cast<size_t>(255);
+    const bool entry = wants_entry_search(ctx);
+    if (int rc = ctx->need(3, fbytes + (entry ? tile_bytes(n_tiles) : 0), &base)) return rc;
     carve_frame(base, n, ctx->sc.n_textures != 0, fb);
+    if (entry) carve_tiles(static_cast<uint8_t*>(base) + fbytes, n_tiles, fb);
     return RT_OK;
 }
 
@@ -710,7 +731,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
     const uint32_t n_lights = ctx->sc.n_lights;
     const uint32_t batch = n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH;
     FrameBufs fb;
-    if (int rc = frame_bufs(ctx, n_out, batch, fb)) return rc;
+    if (int rc = frame_bufs(ctx, n_out, batch, n_waves, fb)) return rc;
     const size_t levels = static_cast<size_t>(max_scatters) + 1;
     // 9 more double planes (ray, raw normal), Fresnel weights, then the 32-bit and 8-bit planes
     const size_t bytes = n_out * (9 * sizeof(double) + max_scatters * sizeof(double) + levels * sizeof(uint32_t)
@@ -732,6 +753,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
         unsigned int* q = nullptr;
         if (int rc = next_queue(ctx, qb, &q)) return rc;
         ctx->mark_begin(0);
+        if (fb.entry_p && level == 0) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
         RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting,
                                  level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill_min));
         ctx->mark_end();
@@ -739,6 +761,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
             const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
             if (int rc = next_queue(ctx, qb, &q)) return rc;
             ctx->mark_begin(1);
+            if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, l0, nb, ctx->counting, &fb, ctx->d_ctr));
             RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                     ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
             ctx->mark_end();
@@ -766,6 +789,7 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     ctx->mark_begin(0);
+    if (fb.entry_p) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
                              &fb, ctx->d_ctr, q, ctx->refill_min));
     ctx->mark_end();
@@ -773,6 +797,7 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
         if (int rc = next_queue(ctx, qb, &q)) return rc;
         ctx->mark_begin(1);
+        if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, l0, nb, ctx->counting, &fb, ctx->d_ctr));
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
         ctx->mark_end();
@@ -787,7 +812,7 @@ int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t 
                  uint8_t* rgb_dev, int32_t* hit_id_dev) {
     const uint32_t n_lights = ctx->sc.n_lights;
     FrameBufs fb;
-    if (int rc = frame_bufs(ctx, n_out, n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH, fb)) return rc;
+    if (int rc = frame_bufs(ctx, n_out, n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH, n_waves, fb)) return rc;
     return run_pipeline_on(ctx, dc, pm, n_waves, n_out, rgb_dev, hit_id_dev, fb, ctx->d_queue);
 }
 
@@ -940,6 +965,9 @@ int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8
     // is written earlier in the same call, so what the previous call left in the workspace is never seen
     FrameBufs fb;
     carve_frame(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes, n_out, ctx->sc.n_textures != 0, fb);
+    const size_t fbytes = (frame_bytes(n_out, batch) + 255u) & ~static_cast<size_t>(255);
+    if (wants_entry_search(ctx) && queue_bytes + fbytes + tile_bytes(nw) <= ctx->static_scratch_bytes)
+        carve_tiles(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes + fbytes, nw, fb);
     return run_pipeline_on(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev, fb, static_cast<unsigned int*>(ctx->static_scratch));
 }
 

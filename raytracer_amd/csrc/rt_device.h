@@ -17,7 +17,11 @@
 #define RT_QUEUE_PARTS 8u          // work-queue heads per launch: one per XCD
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
 #define RT_REFILL_MIN 40           // finished lanes that must pile up before a wave swaps rays (default)
-#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * 80u + 4096u)  // its workspace: 80 bytes per pixel + the queue heads
+#define RT_TILE_BYTES 64u                                             // per 8x8 tile: entry references (4 + 4 * RT_LIGHT_BATCH) and the box of its hits (24)
+// workspace of rt_render_rect_static: 80 bytes per pixel, the queue heads, and the per-tile planes of up to
+// RT_STATIC_MAX_PIXELS / 16 tiles (a rectangle is covered by whole 128 x 128 blocks of tiles, so it can count four times
+// the tiles its pixels fill; beyond that the call goes without the entry search)
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * 80u + 4096u + (RT_STATIC_MAX_PIXELS / 16u) * RT_TILE_BYTES)
 
 struct DevScene {
     const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
@@ -60,7 +64,7 @@ struct FrameBufs {
     double *px, *py, *pz;          // hit point
     double *nx, *ny, *nz;          // unit normal, re-normalised as RayTracer::shade does
     double *lighting;              // running light sum between light batches
-    uint8_t *lit;                  // [light in batch][n] 1 = the light reaches the point (shadow verdict)
+    uint8_t *lit;                  // [n][RT_LIGHT_BATCH] 1 = the light of the batch reaches the point (shadow verdict)
     int32_t *id;                   // primitive whose material applies to the hit, -1 = miss / padding
     uint32_t *slot, *inst;         // what the closest-hit launch found: record slot (all ones = nothing), instance slot
     size_t n;
@@ -70,6 +74,11 @@ struct FrameBufs {
     uint8_t *alive;                // levels >= 1: this slot still carries a ray
     int level;
     uint32_t *albedo;              // scenes with textures only: albedo under the hit, r | g << 8 | b << 16
+    // Entry search (wide, one-level scenes; null otherwise): where the walks of a tile's 64 rays may start instead of
+    // at the root - the deepest node that every ray of the tile's beam has to pass through.
+    uint32_t *entry_p;             // [tiles] camera rays of the tile
+    uint32_t *entry_s;             // [tiles][RT_LIGHT_BATCH] shadow rays of the tile towards one light
+    float    *tile_box;            // [tiles][6] min xyz, max xyz of the tile's hit points (min > max: no hit)
 };
 
 // Per-level results of a mirror-bounce frame, folded into the final colour at the end.
@@ -86,6 +95,10 @@ extern "C" {
 hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                              uint32_t n_tiles, uint32_t n_waves, int counting, int32_t* ids, double* dist,
                              const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
+// Entry references for the beams of n_tiles tiles: camera rays (n_batch = 0) or shadow rays towards lights
+// light0 .. light0 + n_batch - 1 (after the surface records of the tiles are known).
+hipError_t rt_launch_entry_search(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_tiles,
+                                  uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb, rt_counters* ctr);
 hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                             uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);

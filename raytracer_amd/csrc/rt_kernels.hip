@@ -283,6 +283,23 @@ DEV float f32_up(double x) {                       // smallest float >= max(x, 0
     return (f > 0.0f) ? f : 0.0f;
 }
 
+DEV float f32_below(double x) {                    // a float <= x (x finite)
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) > x) {              // one float down
+        const uint32_t u = __float_as_uint(f);
+        f = __uint_as_float(f > 0.0f ? u - 1u : (f == 0.0f ? 0x80000001u : u + 1u));
+    }
+    return f;
+}
+DEV float f32_above(double x) {                    // a float >= x (x finite)
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) < x) {              // one float up
+        const uint32_t u = __float_as_uint(f);
+        f = __uint_as_float(f > 0.0f ? u + 1u : (f == 0.0f ? 1u : u - 1u));
+    }
+    return f;
+}
+
 DEV void box_ray_init(BoxRay& b, const RayD& r, float radius) {
     const float ox = static_cast<float>(r.ox), oy = static_cast<float>(r.oy), oz = static_cast<float>(r.oz);
     const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
@@ -309,6 +326,7 @@ DEV float box_entry(const float4 lo, const float4 hi, const BoxRay& b, float lim
 // A node reference: bits 31..28 = primitive count (0 = internal), bits 27..0 = first slot (leaf) or
 // index of the child pair / 2 (internal).
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t REF_ROOT = 0xFFFFFFFDu;         // "no entry reference: start with the root's box"
 DEV uint32_t make_ref(uint32_t first, uint32_t count) { return count ? (count << 28) | first : (first >> 1); }
 DEV bool ref_internal(uint32_t r) { return (r >> 28) == 0u; }
 
@@ -418,7 +436,9 @@ struct Walker {
     }
 
     // Root box test; afterwards cur is the first node reference or REF_NONE.
-    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist) {
+    // entry: REF_ROOT, or where the walk may start instead - a node every ray of the tile's beam must pass through
+    // (k_entry), REF_NONE when the beam misses the whole tree.
+    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, uint32_t entry = REF_ROOT) {
         r = ray;
         if (INST) { rw = ray; inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
@@ -428,6 +448,7 @@ struct Walker {
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
+        if (WIDE && entry != REF_ROOT) { cur = entry; return; }
         if (WIDE) {
             // the root's box travels with the kernel arguments, with the wide node that holds the root's children
             if (COUNT) vn += 1;
@@ -783,13 +804,15 @@ enum { F_PRIMARY = 0, F_HITS = 1, F_SHADOW = 2, F_BOUNCE = 3, F_VN_P = 4, F_VP_P
 //          surface record the shadow pass starts from.
 //          RECORD & 2: a level of a mirror-bounce frame - deeper levels take their rays from the slots (left there by
 //          k_bounce_resolve).
-// MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) % n_tiles) towards light light0 + (i / 64) / n_tiles;
-//          all 64 rays of a tile aim at the same light.  Writes that light's term of the lighting sum.
+// MODE 1 - shadow rays: ray i = lane (i % 64) of tile ((i / 64) / n_batch) towards light light0 + (i / 64) % n_batch;
+//          the 64 rays of a group aim at one light from one tile, and a tile's lights follow one another, so its
+//          surface records are still in a cache when the next light asks for them.  Writes the verdict.
 template <int MODE, bool COUNT, int RECORD, bool INST = false, bool WIDE = false>
 __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0,
                                              uint32_t n_rays, int32_t* __restrict__ ids, double* __restrict__ dist,
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_batch = MODE == 1 ? (n_rays >> 6) / n_tiles : 1u;      // lights of this shadow launch
     enum { IDLE = 0, TRAV = 1, DONE = 2 };
     uint32_t state = IDLE, out = 0, ridx = 0;
     Walker<MODE, COUNT, INST, WIDE> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
@@ -829,8 +852,8 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     }
                 } else {
                     // only the verdict leaves this kernel: the light's term is evaluated by the resolve kernels, densely
-                    const uint32_t lj = (ridx >> 6) / n_tiles;
-                    fb.lit[static_cast<size_t>(lj) * fb.n + out] = w.blocked() ? 0 : 1;
+                    const uint32_t lj = (ridx >> 6) % n_batch;
+                    fb.lit[static_cast<size_t>(out) * RT_LIGHT_BATCH + lj] = w.blocked() ? 0 : 1;
                 }
                 state = IDLE;
             }
@@ -869,7 +892,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 if (state == IDLE && rank < take) {
                     ridx = rank < take_a ? q_next + rank : b_next + (rank - take_a);
                     const uint32_t g = ridx >> 6;
-                    const Pixel p = map_pixel(pm, MODE == 0 ? g : g % n_tiles, ridx & 63u);
+                    const Pixel p = map_pixel(pm, MODE == 0 ? g : g / n_batch, ridx & 63u);
                     if (p.valid) {
                         out = p.out;
                         if (MODE == 0) {
@@ -886,15 +909,17 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                 primary_ray(cam, p.x, p.y, r);
                             }
                             if (have) {
-                                w.start(sc, r, deep.e, 0.0);
+                                const uint32_t entry = (WIDE && !INST && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p[g] : REF_ROOT;
+                                w.start(sc, r, deep.e, 0.0, entry);
                                 ++n_cast;
                                 state = w.done() ? DONE : TRAV;
                             }
                         } else if (fb.id[out] >= 0) {
-                            const rt_light L = sc.lights[light0 + g / n_tiles];
+                            const rt_light L = sc.lights[light0 + g % n_batch];
                             RayD r;
                             const double ld = shadow_ray(L, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out], r);
-                            w.start(sc, r, deep.e, ld);
+                            const uint32_t entry = (WIDE && !INST && fb.entry_s) ? fb.entry_s[static_cast<size_t>(g / n_batch) * RT_LIGHT_BATCH + g % n_batch] : REF_ROOT;
+                            w.start(sc, r, deep.e, ld, entry);
                             ++n_cast;
                             state = w.done() ? DONE : TRAV;
                         }
@@ -984,36 +1009,169 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
 template <int FLAGS, bool INST>
 __global__ void __launch_bounds__(256) k_surface(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, FrameBufs fb) {
     const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (g >= n_tiles) return;
+    if (g >= n_tiles) return;                                       // whole waves leave together
     const Pixel p = map_pixel(pm, g, threadIdx.x & 63u);
-    if (!p.valid) return;
-    const uint32_t out = p.out;
-    const uint32_t slot = fb.slot[out];
-    RayD r;
-    if ((FLAGS & 2) && fb.level > 0) {
-        if (slot == REF_NONE) { fb.id[out] = -1; return; }          // no ray here, or a miss
-        r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
-        r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
-        r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
-    } else {
-        primary_ray(cam, p.x, p.y, r);
-        if (FLAGS & 2) {
-            fb.ray[out] = r.ox; fb.ray[fb.n + out] = r.oy; fb.ray[2*fb.n + out] = r.oz;
-            fb.ray[3*fb.n + out] = r.dx; fb.ray[4*fb.n + out] = r.dy; fb.ray[5*fb.n + out] = r.dz;
+    float blo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() };
+    float bhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+    if (p.valid) {
+        const uint32_t out = p.out;
+        const uint32_t slot = fb.slot[out];
+        RayD r;
+        bool have = slot != REF_NONE;                               // REF_NONE: no ray here, or a miss
+        if ((FLAGS & 2) && fb.level > 0) {
+            if (have) {
+                r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
+                r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
+                r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
+            }
+        } else {
+            primary_ray(cam, p.x, p.y, r);
+            if (FLAGS & 2) {
+                fb.ray[out] = r.ox; fb.ray[fb.n + out] = r.oy; fb.ray[2*fb.n + out] = r.oz;
+                fb.ray[3*fb.n + out] = r.dx; fb.ray[4*fb.n + out] = r.dy; fb.ray[5*fb.n + out] = r.dz;
+            }
         }
-        if (slot == REF_NONE) { fb.id[out] = -1; return; }
+        if (!have) fb.id[out] = -1;
+        else {
+            Best b; b.dist = 0.0; b.slot = slot; b.id = 0; b.inst = INST ? fb.inst[out] : REF_NONE;
+            HitD h; h.u = 0.0; h.v = 0.0;
+            int32_t mat_id = -1;
+            best_record<(FLAGS & 4) != 0, INST>(sc, b, r, h, mat_id);
+            // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
+            fb.id[out] = mat_id;
+            if (FLAGS & 4) fb.albedo[out] = albedo_at(sc, sc.mats[mat_id], h.u, h.v);
+            double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
+            fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
+            fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
+            if (FLAGS & 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
+            if (fb.tile_box) {
+                blo[0] = f32_below(h.px); blo[1] = f32_below(h.py); blo[2] = f32_below(h.pz);
+                bhi[0] = f32_above(h.px); bhi[1] = f32_above(h.py); bhi[2] = f32_above(h.pz);
+            }
+        }
     }
-    Best b; b.dist = 0.0; b.slot = slot; b.id = 0; b.inst = INST ? fb.inst[out] : REF_NONE;
-    HitD h; h.u = 0.0; h.v = 0.0;
-    int32_t mat_id = -1;
-    best_record<(FLAGS & 4) != 0, INST>(sc, b, r, h, mat_id);
-    // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
-    fb.id[out] = mat_id;
-    if (FLAGS & 4) fb.albedo[out] = albedo_at(sc, sc.mats[mat_id], h.u, h.v);
-    double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
-    fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
-    fb.nx[out] = nx;   fb.ny[out] = ny;   fb.nz[out] = nz;
-    if (FLAGS & 2) { fb.rawn[out] = h.nx; fb.rawn[fb.n + out] = h.ny; fb.rawn[2*fb.n + out] = h.nz; }
+    // the box of the tile's hit points, for the entry search of its shadow beams (every lane of the wave is here)
+    if (fb.tile_box) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                blo[k] = fminf(blo[k], __shfl_xor(blo[k], off, 64));
+                bhi[k] = fmaxf(bhi[k], __shfl_xor(bhi[k], off, 64));
+            }
+        if ((threadIdx.x & 63u) == 0) {
+            float* t = fb.tile_box + static_cast<size_t>(g) * 6u;
+            t[0] = blo[0]; t[1] = blo[1]; t[2] = blo[2]; t[3] = bhi[0]; t[4] = bhi[1]; t[5] = bhi[2];
+        }
+    }
+}
+
+// ---- entry search ------------------------------------------------------------------------------------
+// The 64 rays of a tile form a narrow beam, and near the root they all take the same turns.  One lane per beam walks
+// the wide nodes from the root for as long as the beam can touch only ONE child of the node, and leaves the reference
+// where that ends; the tile's rays then start there.  A child is passed over only when NO ray of the beam can touch
+// its box, so nothing a ray could hit is lost and results do not change; the tests are FP64 and conservative.
+
+// Camera rays of a tile: common origin o, directions within [wlo, whi] per axis (not normalised: a box test does not
+// depend on the direction's length when the ray has no far limit).  Interval arithmetic on the slab test.
+DEV bool beam_touches_primary(const double o[3], const double wlo[3], const double whi[3], const double lo[3], const double hi[3]) {
+    double tn = 0.0, tf = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (wlo[k] <= 0.0 && whi[k] >= 0.0) continue;       // some ray may run along this slab: no constraint from it
+        const double i0 = 1.0 / wlo[k], i1 = 1.0 / whi[k];
+        // entry through the face the directions point away from, exit through the other one
+        const double a = (wlo[k] > 0.0 ? lo[k] : hi[k]) - o[k], b = (wlo[k] > 0.0 ? hi[k] : lo[k]) - o[k];
+        const double near_lb = fmin(a * i0, a * i1), far_ub = fmax(b * i0, b * i1);
+        tn = fmax(tn, near_lb); tf = fmin(tf, far_ub);
+    }
+    return tn <= tf + 1e-9 * fmax(1.0, tf);
+}
+
+// Shadow rays of a tile towards one light: origins within [olo, ohi], all aiming at L.  At parameter t in [0, 1] the rays
+// are inside (1 - t) [olo, ohi] + t L; the box can be touched only if that slice overlaps it for some t, which is six
+// linear conditions on t.  (The rays' 1e-4 nudge along the normal is in the caller's padding of the box.)
+DEV bool beam_touches_shadow(const double olo[3], const double ohi[3], const double L[3], const double lo[3], const double hi[3]) {
+    double tn = 0.0, tf = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // olo + t (L - olo) <= hi
+        { const double b = L[k] - olo[k], r = hi[k] - olo[k];
+          if (b > 0.0) tf = fmin(tf, r / b); else if (b < 0.0) tn = fmax(tn, r / b); else if (r < 0.0) return false; }
+        // ohi + t (L - ohi) >= lo
+        { const double b = ohi[k] - L[k], r = ohi[k] - lo[k];
+          if (b > 0.0) tf = fmin(tf, r / b); else if (b < 0.0) tn = fmax(tn, r / b); else if (r < 0.0) return false; }
+    }
+    return tn <= tf + 1e-9;
+}
+
+// n_batch = 0: beams of camera rays, one per tile -> fb.entry_p.  Otherwise beams of shadow rays, one per tile and light
+// of the batch -> fb.entry_s (needs fb.tile_box from k_surface).
+__global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0, uint32_t n_batch,
+                                               int counting, FrameBufs fb, rt_counters* ctr) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    const bool shadow = n_batch != 0;
+    const uint32_t n_beams = shadow ? n_tiles * n_batch : n_tiles;
+    uint32_t vn = 0;
+    if (b < n_beams) {
+        const uint32_t tile = shadow ? b / n_batch : b;
+        double o_lo[3], o_hi[3], d_lo[3], d_hi[3], L[3];
+        bool any = true;
+        // boxes grow by what the FP64 arithmetic here and the rays' own rounding can lose, and for shadow rays by the
+        // 1e-4 their origins are nudged off the surface (raytracer.cpp:221-225)
+        double pad = 1e-7 * static_cast<double>(sc.radius);
+        if (shadow) {
+            const float* t = fb.tile_box + static_cast<size_t>(tile) * 6u;
+            for (int k = 0; k < 3; ++k) { o_lo[k] = t[k]; o_hi[k] = t[3 + k]; }
+            any = o_lo[0] <= o_hi[0];
+            const rt_light Lt = sc.lights[light0 + b % n_batch];
+            for (int k = 0; k < 3; ++k) { L[k] = Lt.pos[k]; d_lo[k] = 0.0; d_hi[k] = 0.0; }
+            pad += 1.001e-4;
+        } else {
+            const Pixel p = map_pixel(pm, tile, 0u);             // lane 0 is the tile's top left pixel
+            any = p.valid;
+            for (int k = 0; k < 3; ++k) { o_lo[k] = cam.pos[k]; o_hi[k] = cam.pos[k]; L[k] = 0.0; d_lo[k] = __builtin_inf(); d_hi[k] = -__builtin_inf(); }
+            // directions are linear in the pixel coordinates before normalisation (persp_camera.cpp:110-116): their range
+            // over the tile's 8 x 8 pixel squares (sub-pixel offsets included) is spanned by the four corners
+            for (int c = 0; c < 4 && any; ++c) {
+                const double px = static_cast<double>(p.x + ((c & 1) ? 8 : 0)), py = static_cast<double>(p.y + ((c & 2) ? 8 : 0));
+                const double xs = cam.eff_w * (px / cam.width - 0.5), ys = cam.eff_h * (0.5 - py / cam.height), zs = cam.focal;
+                const double w[3] = { cam.rot[0]*xs + cam.rot[1]*ys + cam.rot[2]*zs, cam.rot[3]*xs + cam.rot[4]*ys + cam.rot[5]*zs,
+                                      cam.rot[6]*xs + cam.rot[7]*ys + cam.rot[8]*zs };
+                for (int k = 0; k < 3; ++k) { d_lo[k] = fmin(d_lo[k], w[k]); d_hi[k] = fmax(d_hi[k], w[k]); }
+            }
+            double wmax = 0.0;
+            for (int k = 0; k < 3; ++k) wmax = fmax(wmax, fmax(fabs(d_lo[k]), fabs(d_hi[k])));
+            for (int k = 0; k < 3; ++k) { d_lo[k] -= 1e-9 * wmax; d_hi[k] += 1e-9 * wmax; }
+        }
+        auto touches = [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
+            const double lo[3] = { lx - pad, ly - pad, lz - pad }, hi[3] = { hx + pad, hy + pad, hz + pad };
+            return shadow ? beam_touches_shadow(o_lo, o_hi, L, lo, hi) : beam_touches_primary(o_lo, d_lo, d_hi, lo, hi);
+        };
+        uint32_t node = REF_NONE;
+        if (any) {
+            vn += 1;
+            if (touches(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2], sc.root_hi[0], sc.root_hi[1], sc.root_hi[2])) node = sc.root_ref;
+        }
+        // the tree is at most 31 levels deep; the bound only guards against a malformed one
+        for (int depth = 0; depth < 64 && node != REF_NONE && ref_internal(node); ++depth) {
+            const float4* n4 = sc.nodes4 + 8u * static_cast<size_t>(node);
+            const float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5], rf = n4[6];
+            vn += 4;
+            const uint32_t r[4] = { __float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w) };
+            const bool h[4] = { r[0] != REF_NONE && touches(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x),
+                                r[1] != REF_NONE && touches(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y),
+                                r[2] != REF_NONE && touches(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z),
+                                r[3] != REF_NONE && touches(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w) };
+            const int nh = int(h[0]) + int(h[1]) + int(h[2]) + int(h[3]);
+            if (nh == 0) { node = REF_NONE; break; }
+            if (nh > 1) break;
+            node = h[0] ? r[0] : (h[1] ? r[1] : (h[2] ? r[2] : r[3]));
+        }
+        if (shadow) fb.entry_s[static_cast<size_t>(tile) * RT_LIGHT_BATCH + b % n_batch] = node;
+        else        fb.entry_p[tile] = node;
+    }
+    if (counting) add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, shadow ? F_VN_S : F_VN_P, vn);
 }
 
 // The terms of the lights of one batch that reach surface point i, added in light order (the reference's accumulation
@@ -1022,7 +1180,7 @@ DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, size_t i, uin
                           double vox, double voy, double voz, double lighting) {
     const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
     for (uint32_t j = 0; j < n_batch; ++j) {
-        if (!fb.lit[static_cast<size_t>(j) * fb.n + i]) continue;
+        if (!fb.lit[i * RT_LIGHT_BATCH + j]) continue;
         const rt_light L = sc.lights[light0 + j];
         double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
         lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, vox, voy, voz);
@@ -1332,6 +1490,15 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
 #undef RT_LAUNCH_SURFACE
 #undef RT_LAUNCH_PRIMARY_I
 #undef RT_LAUNCH_PRIMARY_IW
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_entry_search(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_tiles,
+                                             uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb, rt_counters* ctr) {
+    const uint64_t n_beams = static_cast<uint64_t>(n_tiles) * (n_batch ? n_batch : 1u);
+    if (!sc->nodes4 || sc->inst || !fb || !fb->entry_p || n_beams == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_entry, dim3(static_cast<uint32_t>((n_beams + 255u) / 256u)), dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch,
+                       counting, *fb, ctr);
     return hipGetLastError();
 }
 

@@ -190,15 +190,25 @@ def test_counting_kernels_match_the_cpu_walk(ctx, oracle):
         sc = capi.Scene.create(prims, lights, max_leaf=max_leaf)
         ctx.upload(sc)
         ctx.set_counting(True)
+        ctx.set_entry_search(False)            # the CPU restatement starts every walk at the root
         ctx.reset_counters()
         rgb, ids = ctx.render(cam, max_scatters=0, want_ids=True)
         c = ctx.counters()
-        ctx.set_counting(False)
         want_ids, want_rgb, counts, hits = oracle.bvh_render(oracle.scene(prims, lights), oracle_bvh(oracle, sc), ocamera(cam))
         assert np.array_equal(ids, want_ids)
         assert_rgb_close(rgb, want_rgb, max_frac=1e-3)
         assert c["primary_hits"] == hits and c["shadow_rays"] == hits * 4
         assert [c["nodes_primary"], c["prims_primary"], c["nodes_shadow"], c["prims_shadow"]] == list(counts)
+        # walks that start where the tile's beam allows: the same frame from fewer boxes (the search's own included)
+        ctx.set_entry_search(True)
+        ctx.reset_counters()
+        rgb_e, ids_e = ctx.render(cam, max_scatters=0, want_ids=True)
+        ce = ctx.counters()
+        ctx.set_counting(False)
+        assert np.array_equal(ids_e, ids) and np.array_equal(rgb_e, rgb)
+        assert ce["nodes_primary"] < c["nodes_primary"] and ce["nodes_shadow"] < c["nodes_shadow"]
+        assert ce["prims_primary"] <= c["prims_primary"] and ce["prims_shadow"] <= c["prims_shadow"]
+        assert ce["primary_hits"] == hits and ce["shadow_rays"] == hits * 4
         # the plain kernels give the same picture and leave the fetch counters alone
         ctx.reset_counters()
         rgb2 = ctx.render(cam, max_scatters=0)
@@ -597,10 +607,10 @@ def test_hierarchy_built_on_the_device(ctx, oracle, name, cam_id):
         assert len(wide) == 2 * info.n_slots                # the builder wrote wide nodes beside the binary ones
     b = oracle.bvh(nodes, slots, info.n_slots, info.n_loose, radius, wide)
     _, _, counts, hits = oracle.bvh_render(oracle.scene(prims, lights), b, ocamera(cam))
-    ctx.set_counting(True); ctx.reset_counters()
+    ctx.set_counting(True); ctx.set_entry_search(False); ctx.reset_counters()     # the CPU walk starts at the root
     ctx.render(cam, max_scatters=0)
     c = ctx.counters()
-    ctx.set_counting(False)
+    ctx.set_counting(False); ctx.set_entry_search(True)
     if len(lights):
         assert [c["nodes_primary"], c["prims_primary"], c["nodes_shadow"], c["prims_shadow"]] == counts.tolist()
         assert c["primary_hits"] == hits
