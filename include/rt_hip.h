@@ -232,6 +232,10 @@ int rt_shade_hits(rt_ctx* ctx, const double* hits10_dev, const double* view3_dev
  * rect.w * rect.h * 3 bytes; hit_id_dev (may be NULL) receives the primary hit ids. */
 int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatters, double min_scatter_intensity,
                    uint8_t* rgb_dev, int32_t* hit_id_dev);
+/* The shadow test of RayTracer::shade alone (raytracer.cpp:210-240) for the primary hit of every pixel of the rectangle:
+ * one byte per pixel, bit l set = point light l (file order, at most 8 lights: RT_ERR_LIMIT beyond) is NOT blocked, i.e.
+ * no closest hit of the shadow ray lies in (1e-4, distance to the light - 1e-4); 0 where the camera ray hits nothing. */
+int rt_trace_shadows(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* lit_mask_dev);
 /* rt_render_rect with max_scatters = 0 for callers that cannot allocate device memory: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The frame working
  * set (80 bytes per pixel: hit points, normals, light sums, record slots, shadow verdicts) and the work-queue heads

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("rt_shade_hits", C.c_int, [_VP, _VP, _VP, _U64, _VP]),
     ("rt_render_samples", C.c_int, [_VP, C.POINTER(Camera), Rect, C.c_int, _U32, C.c_int, _D, _VP]),
     ("rt_render_rect", C.c_int, [_VP, C.POINTER(Camera), Rect, C.c_int, _D, _VP, _VP]),
+    ("rt_trace_shadows", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP]),
     ("rt_render_rect_static", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP, _VP]),
     ("rt_render_tiles", C.c_int, [_VP, C.POINTER(Camera), Tiling, C.c_int, C.c_int, _D, _VP]),
     ("rt_assemble_tiles", C.c_int, [_VP, Tiling, _VP, _VP]),
@@ -450,6 +451,10 @@ class Context:
 
     def render_rect_dev(self, cam, rect, rgb_ptr, ids_ptr=None, max_scatters=0, min_scatter_intensity=0.0):
         _check(lib().rt_render_rect(self.h, C.byref(cam), Rect(*rect), max_scatters, min_scatter_intensity, rgb_ptr, ids_ptr))
+
+    def trace_shadows_dev(self, cam, rect, mask_ptr):
+        """One byte per pixel: bit l set = light l reaches the pixel's primary hit."""
+        _check(lib().rt_trace_shadows(self.h, C.byref(cam), Rect(*rect), mask_ptr))
 
     def render_rect_static_dev(self, cam, rect, rgb_ptr, ids_ptr=None):
         """rt_render_rect (no bounces) on the library's fixed workspace: no device allocation; at most 262144 pixels."""

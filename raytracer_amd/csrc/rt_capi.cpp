@@ -808,6 +808,25 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     return RT_OK;
 }
 
+// The same up to the verdicts: which lights reach each pixel's hit (first batch of lights only).
+int run_shadow_mask(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out, uint8_t* mask_dev) {
+    const uint32_t n_lights = ctx->sc.n_lights;
+    FrameBufs fb;
+    if (int rc = frame_bufs(ctx, n_out, n_lights, n_waves, fb)) return rc;
+    QueueBlock qb(ctx->d_queue);
+    unsigned int* q = nullptr;
+    if (int rc = next_queue(ctx, qb, &q)) return rc;
+    if (fb.entry_p) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
+    RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, nullptr, nullptr,
+                             &fb, ctx->d_ctr, q, ctx->refill_min));
+    if (int rc = next_queue(ctx, qb, &q)) return rc;
+    if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, n_lights, ctx->counting, &fb, ctx->d_ctr));
+    RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * n_lights), 0, n_lights,
+                            ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
+    RT_HIP(rt_launch_verdict_mask(ctx->stream, &fb, n_lights, mask_dev));
+    return RT_OK;
+}
+
 int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out,
                  uint8_t* rgb_dev, int32_t* hit_id_dev) {
     const uint32_t n_lights = ctx->sc.n_lights;
@@ -935,6 +954,18 @@ int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatter
 }
 
 } // namespace
+
+int rt_trace_shadows(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* lit_mask_dev) {
+    if (int rc = need_scene(ctx)) return rc;
+    if (!camera_ok(cam) || !lit_mask_dev) return fail(RT_ERR_INVALID, "bad camera or null output");
+    if (ctx->sc.n_lights > RT_LIGHT_BATCH) return fail(RT_ERR_LIMIT, "rt_trace_shadows: more than 8 lights");
+    PixelMap pm; uint32_t nw = 0;
+    if (int rc = rect_map(cam, rect, pm, nw)) return rc;
+    const size_t n_out = static_cast<size_t>(rect.w) * rect.h;
+    if (ctx->sc.n_lights == 0) { RT_HIP(hipMemsetAsync(lit_mask_dev, 0, n_out, ctx->stream)); return RT_OK; }
+    DevCamera dc; to_dev_camera(*cam, dc);
+    return run_shadow_mask(ctx, dc, pm, nw, n_out, lit_mask_dev);
+}
 
 int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* rgb_dev, int32_t* hit_id_dev) {
     if (int rc = need_scene(ctx)) return rc;

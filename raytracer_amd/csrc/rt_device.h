@@ -104,6 +104,7 @@ hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera*
                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
 hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, uint32_t light0, uint32_t n_batch,
                              int first, int last, uint8_t* rgb);
+hipError_t rt_launch_verdict_mask(hipStream_t st, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr);
 hipError_t rt_launch_accumulate(hipStream_t st, const uint8_t* rgb, uint32_t* acc, size_t n, int first);

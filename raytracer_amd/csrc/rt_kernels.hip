@@ -1206,6 +1206,16 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, Fra
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
 }
 
+// One byte per output slot: bit j set = light j of the batch reaches the slot's surface point; 0 where nothing was hit.
+__global__ void __launch_bounds__(256) k_verdict_mask(FrameBufs fb, uint32_t n_batch, uint8_t* __restrict__ mask) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= fb.n) return;
+    uint32_t m = 0;
+    if (fb.id[i] >= 0)
+        for (uint32_t j = 0; j < n_batch; ++j) m |= fb.lit[i * RT_LIGHT_BATCH + j] ? (1u << j) : 0u;
+    mask[i] = static_cast<uint8_t>(m);
+}
+
 // Arbitrary rays (origin, direction as 6 doubles): closest hit, optionally shaded (linear colour, no gamma).
 template <bool COUNT, bool SHADE, bool INST = false, bool WIDE = false>
 __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __restrict__ rays, uint64_t n,
@@ -1521,6 +1531,12 @@ extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, cons
                                         uint32_t n_batch, int first, int last, uint8_t* rgb) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
     if (nb) hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *fb, light0, n_batch, first, last, rgb);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_verdict_mask(hipStream_t st, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask) {
+    const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
+    if (nb) hipLaunchKernelGGL(k_verdict_mask, dim3(nb), dim3(256), 0, st, *fb, n_batch, mask);
     return hipGetLastError();
 }
 

@@ -1,9 +1,21 @@
-"""GPU parity at the benchmark configurations' sizes.  Brute force is out of reach there, so the frame is checked
-(a) on strided pixel samples against the CPU oracle walking the same BVH (itself proven equal to brute force
-at small sizes), and (b) through size-independent properties: tile partition == single launch, ids from the
-trace kernel == ids from the render kernel, counters consistent with the id plane, triangle ids / 12 == cube ids."""
+"""GPU parity at the benchmark configurations' sizes, against fixtures that owe nothing to the product's hierarchy
+(oracle/make_golden_large.py, made in the development container):
+  config3_sample / config4_sample - 65 536 / 16 384 seeded pixels of the 4K / 8K frame over the 1M-cell scene, every
+      primary and shadow ray resolved by the oracle's loop over ALL 1.33 M primitives: ids, FP64 distances, one verdict
+      bit per light, linear colour;
+  config3_ref_bvh_ids - the id of every pixel of the 4K frame from the REAL reference's own hierarchy
+      (get_BVH_tree + accelerated_one_pass_intersection) over the same cells built through its public constructors;
+  config5_sample - 65 536 pixels of the all-mirror instanced scene with two bounces, from the oracle's loop over all
+      instances.
+Beside them: strided samples against the CPU walk of the product's own tree, and size-independent properties - tile
+partition == single launch, ids of the trace kernel == ids of the render kernel, counters consistent with the id plane,
+triangle ids / 12 == cube ids."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import GOLDEN
 
 from raytracer_amd import capi
 from raytracer_amd import scenes as S
@@ -30,6 +42,37 @@ def oracle_bvh(oracle, sc):
 def ocamera(cam):
     from oracle import bind
     return bind.Camera.from_buffer_copy(bytes(cam))
+
+
+def load_fixture(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def check_sample(ctx, cam, g, rgb, ids, dist, mask):
+    """A frame's planes against a brute-force fixture at the fixture's pixels: ids and FP64 distances exact, shadow
+    verdicts exact, colour within +-1 of the fixture's linear colour (under the display transfer table)."""
+    px, py = g["px"].astype(np.int64), g["py"].astype(np.int64)
+    assert np.array_equal(ids[py, px], g["id"])
+    assert np.array_equal(bits(dist[py, px]), bits(g["dist"]))
+    assert np.array_equal(mask[py, px], g["lit_mask"])
+    lut = capi.gamma_lut().astype(np.int16)
+    lin = g["rgb_linear"].astype(np.int16)
+    got = rgb[py, px].astype(np.int16)
+    ok = (got >= lut[np.clip(lin - 1, 0, 255)]) & (got <= lut[np.clip(lin + 1, 0, 255)])
+    assert ok.all()
+    assert (got != lut[lin]).any(-1).mean() < 1e-3
+    return int((g["id"] >= 0).sum())
+
+
+def frame_planes(ctx, cam, W, H):
+    import torch
+    rgb, ids = ctx.render(cam, max_scatters=0, want_ids=True)
+    tids, dist = ctx.trace_primary(cam)
+    assert np.array_equal(tids, ids)
+    mask = torch.empty(H * W, dtype=torch.uint8, device="cuda")
+    ctx.trace_shadows_dev(cam, (0, 0, W, H), mask.data_ptr())
+    ctx.synchronize()
+    return rgb, ids, dist, mask.cpu().numpy().reshape(H, W)
 
 
 def test_medium_mixed_field_full_frame(ctx, oracle):
@@ -78,21 +121,23 @@ def test_one_million_cells_4k(ctx, oracle):
     assert np.array_equal(ids[::step, ::step], want_ids)
     diff = np.abs(rgb[::step, ::step].astype(np.int16) - want_rgb.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).any(-1).mean() < 1e-3
-    # brute force on 256 rays (1.3M primitive tests each)
-    rng = np.random.default_rng(11)
-    px, py = rng.integers(0, W, 256), rng.integers(H // 3, H, 256)
-    rays = capi.pixel_rays(cam, np.stack([px + 0.5, py + 0.5], axis=1))
-    brute = oracle.trace_rays(oracle.scene(prims, lights), rays)
-    assert np.array_equal(ids[py, px], brute["id"])
-    assert np.array_equal(bits(tdist[py, px]), bits(brute["dist"]))
-    # shadow verdicts by brute force on 64 of them: shade() with every primitive tested for every shadow ray
-    sub = np.ascontiguousarray(rays[:64])
-    want_lin = oracle.shade_rays(oracle.scene(prims, lights), sub)
+    # brute force (the reference's algorithm: every ray against all 1.33 M primitives) on 65 536 seeded pixels: ids,
+    # distances, shadow verdicts per light, colour
+    g = load_fixture("config3_sample")
+    assert tuple(g["res"]) == (W, H) and int(g["n_prims"]) == len(prims)
+    mask = torch.empty(H * W, dtype=torch.uint8, device="cuda")
+    ctx.trace_shadows_dev(cam, (0, 0, W, H), mask.data_ptr())
+    ctx.synchronize()
+    assert check_sample(ctx, cam, g, rgb, ids, tdist, mask.cpu().numpy().reshape(H, W)) > 50000
+    # the arbitrary-ray kernels on a part of the same sample (they walk the tree in one go, lane by lane)
+    sub = capi.pixel_rays(cam, np.stack([g["px"][:4096] + 0.5, g["py"][:4096] + 0.5], axis=1))
+    gid, gdist = ctx.trace_rays(sub)
+    assert np.array_equal(gid, g["id"][:4096]) and np.array_equal(bits(gdist), bits(g["dist"][:4096]))
     rt = torch.from_numpy(sub).cuda()
     lin = torch.empty((len(sub), 3), dtype=torch.uint8, device="cuda")
     ctx.shade_rays_dev(rt.data_ptr(), len(sub), lin.data_ptr())
     ctx.synchronize()
-    assert want_lin.any() and np.abs(lin.cpu().numpy().astype(np.int16) - want_lin.astype(np.int16)).max() <= 1
+    assert np.abs(lin.cpu().numpy().astype(np.int16) - g["rgb_linear"][:4096].astype(np.int16)).max() <= 1
     # the 8-GPU partition on this frame: 8 virtual ranks, 64-pixel tiles
     tiling = capi.Tiling(W, H, 64, 8)
     per = capi.tiles_per_rank(tiling) * 64 * 64 * 3
@@ -103,6 +148,40 @@ def test_one_million_cells_4k(ctx, oracle):
     ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
     ctx.synchronize()
     assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), rgb)
+
+
+def test_one_million_cells_against_the_reference_hierarchy(ctx):
+    """Every pixel of the 4K frame against the REAL reference's own BVH path (valid for camera rays: the camera is
+    outside the scene's bounds).  The reference has no triangle, so its scene holds each parallelogram as a Plane: the
+    product is checked on that scene id for id, and on the benchmark's scene (two triangles per parallelogram) through
+    the map from triangle pairs to planes."""
+    W, H = 3840, 2160
+    want = load_fixture("config3_ref_bvh_ids")["ids"]
+    cam = capi.make_camera(**S.mixed_field_camera(res=(W, H)))
+    lights = S.mixed_field_lights()
+    planes = S.mixed_field(n_side=1000, seed=0x100000, planes_as_triangles=False)
+    assert len(planes) == int(load_fixture("config3_ref_bvh_ids")["n_prims"])
+    ctx.upload(capi.Scene.create(planes, lights))
+    ids, _ = ctx.trace_primary(cam)
+    assert np.array_equal(ids, want)
+    tris = S.mixed_field(n_side=1000, seed=0x100000)
+    ctx.upload(capi.Scene.create(tris, lights))
+    tid, _ = ctx.trace_primary(cam)
+    # reference order: cubes, planes, spheres (, triangles).  In the plane scene the planes are the parallelograms in
+    # cell order followed by the ground; in the triangle scene the ground is the only plane and the triangles come last,
+    # two per parallelogram in the same cell order.
+    n_cubes = int((tris["kind"] == S.CUBE).sum())
+    n_quads = int((planes["kind"] == S.PLANE).sum()) - 1
+    first_tri = int(np.argmax(tris["kind"] == S.TRIANGLE))
+    assert first_tri + 2 * n_quads == len(tris)
+    to_plane_scene = np.empty(len(tris) + 1, dtype=np.int64)
+    to_plane_scene[-1] = -1                                              # a miss stays a miss
+    to_plane_scene[:n_cubes] = np.arange(n_cubes)
+    to_plane_scene[n_cubes] = n_cubes + n_quads                          # the ground
+    n_sph = first_tri - n_cubes - 1
+    to_plane_scene[n_cubes + 1:first_tri] = n_cubes + n_quads + 1 + np.arange(n_sph)
+    to_plane_scene[first_tri:len(tris)] = n_cubes + np.arange(2 * n_quads) // 2
+    assert np.array_equal(to_plane_scene[tid], want)
 
 
 def test_cube_field_as_triangles(ctx, oracle):
@@ -188,6 +267,26 @@ def test_8k_frame(ctx, oracle):
     assert np.array_equal(ids[::step, ::step], want_ids)
     diff = np.abs(rgb[::step, ::step].astype(np.int16) - want_rgb.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).any(-1).mean() < 1e-3
+    # brute force over all primitives on 16 384 seeded pixels of this frame
+    import torch
+    g = load_fixture("config4_sample")
+    assert tuple(g["res"]) == (W, H)
+    _, dist = ctx.trace_primary(cam)
+    mask = torch.empty(H * W, dtype=torch.uint8, device="cuda")
+    ctx.trace_shadows_dev(cam, (0, 0, W, H), mask.data_ptr())
+    ctx.synchronize()
+    assert check_sample(ctx, cam, g, rgb, ids, dist, mask.cpu().numpy().reshape(H, W)) > 12000
+    del mask, dist
+    # the partition this frame is rendered with on 8 GPUs, as 8 virtual ranks on this one: the same bytes
+    tiling = capi.Tiling(W, H, 64, 8)
+    per = capi.tiles_per_rank(tiling) * 64 * 64 * 3
+    gathered = torch.empty(8 * per, dtype=torch.uint8, device="cuda")
+    for r in range(8):
+        ctx.render_tiles_dev(cam, tiling, r, gathered.data_ptr() + r * per, 0, 0.0)
+    frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
+    ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), rgb)
 
 
 def test_device_built_hierarchy_at_a_million_primitives(ctx):
@@ -260,3 +359,27 @@ def test_hundred_million_instanced_triangles(ctx, oracle):
     ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
     ctx.synchronize()
     assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), full)
+
+
+def test_all_mirror_instanced_scene_against_the_fixture(ctx):
+    """The 100 M-triangle scene as the benchmark configuration states it - every material a mirror, two bounces - on
+    65 536 seeded pixels against the oracle's loop over all instances (no hierarchy involved): primary ids and distances
+    exact, colour after two bounces and without bounces within +-1 of the fixture's linear colour."""
+    prims, inst, lights, camd = S.instanced_field(mirror=True)
+    g = load_fixture("config5_sample")
+    W, H = camd["res"]
+    assert tuple(g["res"]) == (W, H) and int(g["n_instances"]) == len(inst) and int(g["n_mesh_prims"]) == len(prims)
+    ctx.upload(capi.Scene.create_instanced(prims, inst, lights))
+    cam = capi.make_camera(**camd)
+    px, py = g["px"].astype(np.int64), g["py"].astype(np.int64)
+    ids, dist = ctx.trace_primary(cam)
+    assert np.array_equal(ids[py, px], g["id"]) and (g["id"] >= 0).sum() > 20000
+    assert np.array_equal(bits(dist[py, px]), bits(g["dist"]))
+    lut = capi.gamma_lut().astype(np.int16)
+    for ms, key in ((2, "rgb_linear_2_bounces"), (0, "rgb_linear_0_bounces")):
+        rgb = ctx.render(cam, max_scatters=ms)
+        lin = g[key].astype(np.int16)
+        got = rgb[py, px].astype(np.int16)
+        ok = (got >= lut[np.clip(lin - 1, 0, 255)]) & (got <= lut[np.clip(lin + 1, 0, 255)])
+        assert ok.all(), ms
+        assert (got != lut[lin]).any(-1).mean() < 2e-3, ms
