@@ -8,8 +8,9 @@
 One step = one full frame through the hot path (primary rays, closest hit, one shadow ray per light per
 hit, Blinn-Phong, gamma) with the scene already resident in HBM.  With N > 1 the SAME frame is split into
 64x64 tiles dealt round-robin over the ranks (scene replicated), each rank renders its tiles, the tiles are
-gathered to rank 0 over RCCL and scattered into the frame there; that gather + assembly is inside the timed
-region, so per-N values are strong scaling of one frame.
+gathered to rank 0 over RCCL (rt_gather_tiles of the C ABI: one send per peer, grouped receives on rank 0) and
+scattered into the frame there; that gather + assembly is inside the timed region, so per-N values are strong
+scaling of one frame.
 
 Ray count per frame = W*H primary + (#primary hits) * (#lights) shadow rays, exactly as the reference casts
 them (s2899221/Code/raytracer.cpp:210-240).  Rank 0 prints ONE JSON line.
@@ -173,14 +174,26 @@ def main():
         def step():
             ctx.render_rect_dev(cam, (0, 0, W, H), frame.data_ptr(), None, args.max_scatters, 0.0)
     else:
-        from raytracer_amd import tiles
-        tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
         frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda") if rank == 0 else None
-        def step():
-            ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
-            gathered = tg.gather()
+        if rehearsal:
+            from raytracer_amd import tiles
+            tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
+            def step():
+                ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
+                gathered = tg.gather()
+                if rank == 0:
+                    ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+        else:
+            # the C ABI's own exchange: rank 0 names the group, the id travels over torch.distributed, every rank joins
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
-                ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+                uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            comm = capi.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+            local = torch.zeros(capi.tiles_per_rank(tiling) * args.tile * args.tile * 3, dtype=torch.uint8, device="cuda")
+            def step():
+                ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
+                comm.gather_tiles(tiling, local.data_ptr(), frame.data_ptr() if rank == 0 else None)
 
     def fence():
         if dist is not None:
@@ -261,7 +274,7 @@ def main():
                 "n_side": args.n_side, "n_prims": int(info.n_instanced_prims if args.instanced else info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
                 "wide_nodes": (2 * int(info.n_slots) if ctx.build_time_ms() > 0 else scene.n_wide()),
                 "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
-                "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world
+                "partition": ("image tiles round-robin over %d ranks, scene replicated, rt_gather_tiles (RCCL send / grouped recv) to rank 0" % world
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
                 "shadow_rays": total["shadow_rays"], "bounce_rays": total["bounce_rays"], "scene_build_s": round(build_s, 3),

@@ -32,7 +32,8 @@ typedef enum rt_status {
     RT_ERR_HIP = -5,          /* a HIP call failed; rt_last_error() has the text */
     RT_ERR_NO_SCENE = -6,     /* trace/render called before rt_scene_upload */
     RT_ERR_LIMIT = -7,        /* size beyond a documented maximum */
-    RT_ERR_PARSE = -8         /* malformed number in a scene file */
+    RT_ERR_PARSE = -8,        /* malformed number in a scene file */
+    RT_ERR_COMM = -9          /* RCCL missing or an RCCL call failed; rt_last_error() has the text */
 } rt_status;
 
 enum { RT_CUBE = 0, RT_PLANE = 1, RT_CYLINDER = 2, RT_SPHERE = 3, RT_TRIANGLE = 4 };
@@ -260,6 +261,31 @@ int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int ran
                     double min_scatter_intensity, uint8_t* rgb_dev);
 /* Scatter the gathered per-rank tile buffers (rank-major, as rt_render_tiles wrote them) into a row-major frame. */
 int rt_assemble_tiles(rt_ctx* ctx, rt_tiling tiling, const uint8_t* gathered_dev, uint8_t* frame_rgb_dev);
+/* The exchange of a tiled frame: every rank's tile buffer (as rt_render_tiles wrote it) travels to rank 0 by RCCL
+ * point-to-point over xGMI - one send per peer, the matching receives on rank 0 in one group, no ring and no reduction -
+ * and rank 0 scatters them into the row-major frame (the assemble kernel), all ordered on each context's stream.  The
+ * reference has no counterpart: it is one thread on one CPU (render loop raytracer.cpp:401-438).
+ *   One process (or host thread) per GPU: rank 0 makes an id (rt_comm_unique_id), hands its 128 bytes to the others by
+ *   any channel, every rank calls rt_comm_create, then rt_gather_tiles once per frame (frame_rgb_dev is read on rank 0
+ *   only and may be NULL elsewhere).
+ *   One process driving n GPUs: rt_comm_create_all over n contexts (one GPU each, in rank order), then
+ *   rt_gather_tiles_all with every rank's tile buffer; the frame lands on the GPU of contexts[0].
+ * n_ranks = 1 works (rank 0 copies and scatters its own tiles).  RCCL is looked up at first use: without it these
+ * calls return RT_ERR_COMM and everything else works.  A failing RCCL call returns RT_ERR_COMM with its text in
+ * rt_last_error(); a communicator that failed is not usable afterwards. */
+#define RT_COMM_ID_BYTES 128
+typedef struct rt_comm rt_comm;
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+int rt_comm_create(rt_ctx* ctx, int n_ranks, int rank, const uint8_t id[RT_COMM_ID_BYTES], rt_comm** out);
+int rt_comm_create_all(rt_ctx** ctxs, int n, rt_comm** comms_out);
+int rt_comm_destroy(rt_comm* comm);
+int rt_gather_tiles(rt_comm* comm, rt_tiling tiling, const uint8_t* tiles_dev, uint8_t* frame_rgb_dev);
+int rt_gather_tiles_all(rt_comm** comms, int n, rt_tiling tiling, const uint8_t* const* tiles_dev, uint8_t* frame_rgb_dev);
+/* render_unaccelerated_ppm's frame (samples_per_pixel = 1, raytracer.cpp:373-442) on the n GPUs of a group made with
+ * rt_comm_create_all, for host-memory callers: every GPU renders its tiles of `tile` x `tile` pixels, rt_gather_tiles_all
+ * brings them to the first GPU, the frame is copied to rgb_host.  Each context must hold the scene.  Synchronises. */
+int rt_render_frame_multi_host(rt_comm** comms, int n, const rt_camera* cam, int tile, int max_scatters,
+                               double min_scatter_intensity, uint8_t* rgb_host);
 int32_t rt_tiles_per_rank(rt_tiling tiling);
 int32_t rt_tile_count(rt_tiling tiling);
 

@@ -23,7 +23,7 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"] + os.environ.get("RT_EXTRA_FLAGS", "").split()
 DEVICE_SOURCES = ["rt_kernels.hip", "rt_gpu_build.hip"]
-HOST_SOURCES = ["rt_capi.cpp", "rt_scene.cpp", "rt_prep.cpp", "rt_bvh.cpp", "rt_json.cpp", "rt_image.cpp"]
+HOST_SOURCES = ["rt_capi.cpp", "rt_comm.cpp", "rt_scene.cpp", "rt_prep.cpp", "rt_bvh.cpp", "rt_json.cpp", "rt_image.cpp"]
 
 
 def hipcc():
@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             _run(cmd)
     if force or _stale(LIB, objs):
-        _run([cc, "-shared", "-o", LIB, "--offload-arch=" + ARCH] + objs)
+        _run([cc, "-shared", "-o", LIB, "--offload-arch=" + ARCH] + objs + ["-ldl"])
     # C++ mirror of the reference's class API + its two command-line drivers, on top of the C ABI
     host_dir = os.path.join(CSRC, "host")
     if os.path.isdir(host_dir):

@@ -18,7 +18,7 @@ NODE4_DT = np.dtype([("lo", "<f4", (3, 4)), ("hi", "<f4", (3, 4)), ("ref", "<u4"
 
 RT_OK = 0
 STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_IO", -3: "RT_ERR_NOT_FOUND", -4: "RT_ERR_NO_DEVICE",
-          -5: "RT_ERR_HIP", -6: "RT_ERR_NO_SCENE", -7: "RT_ERR_LIMIT", -8: "RT_ERR_PARSE"}
+          -5: "RT_ERR_HIP", -6: "RT_ERR_NO_SCENE", -7: "RT_ERR_LIMIT", -8: "RT_ERR_PARSE", -9: "RT_ERR_COMM"}
 
 
 class RtError(RuntimeError):
@@ -114,6 +114,13 @@ SYMBOLS = [
     ("rt_render_rect_static", C.c_int, [_VP, C.POINTER(Camera), Rect, _VP, _VP]),
     ("rt_render_tiles", C.c_int, [_VP, C.POINTER(Camera), Tiling, C.c_int, C.c_int, _D, _VP]),
     ("rt_assemble_tiles", C.c_int, [_VP, Tiling, _VP, _VP]),
+    ("rt_comm_unique_id", C.c_int, [_VP]),
+    ("rt_comm_create", C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
+    ("rt_comm_create_all", C.c_int, [C.POINTER(_VP), C.c_int, C.POINTER(_VP)]),
+    ("rt_comm_destroy", C.c_int, [_VP]),
+    ("rt_gather_tiles", C.c_int, [_VP, Tiling, _VP, _VP]),
+    ("rt_gather_tiles_all", C.c_int, [C.POINTER(_VP), C.c_int, Tiling, C.POINTER(_VP), _VP]),
+    ("rt_render_frame_multi_host", C.c_int, [C.POINTER(_VP), C.c_int, C.POINTER(Camera), C.c_int, C.c_int, _D, _VP]),
     ("rt_tiles_per_rank", _I32, [Tiling]),
     ("rt_tile_count", _I32, [Tiling]),
     ("rt_counters_reset", C.c_int, [_VP]),
@@ -514,6 +521,38 @@ class Context:
         rgb = np.empty((cam.height, cam.width, 3), dtype=np.uint8)
         _check(lib().rt_render_samples_host(self.h, C.byref(cam), spp, seed, max_scatters, min_scatter_intensity, _ptr(rgb)))
         return rgb
+
+
+def comm_unique_id():
+    """128 bytes that name a new group of ranks (rank 0 makes them, every rank passes them to Comm)."""
+    buf = (C.c_uint8 * 128)()
+    _check(lib().rt_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """One rank of a group of GPUs (rt_comm): RCCL point-to-point gather of tile buffers to rank 0."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        assert len(unique_id) == 128
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib().rt_comm_create(ctx.h, n_ranks, rank, buf, C.byref(h)))
+        self.h, self.ctx, self.n_ranks, self.rank = h, ctx, n_ranks, rank
+
+    def gather_tiles(self, tiling, tiles_ptr, frame_ptr=None):
+        _check(lib().rt_gather_tiles(self.h, tiling, tiles_ptr, frame_ptr))
+
+    def close(self):
+        if self.h:
+            lib().rt_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tiles_per_rank(tiling):

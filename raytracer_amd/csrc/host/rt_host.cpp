@@ -27,14 +27,27 @@ static int device_index() {
     return env ? std::atoi(env) : 0;
 }
 
-// One context per scene: a context holds one uploaded scene at a time.
+// RT_GPUS=n (n > 1): frames are rendered on GPUs device .. device + n - 1, image tiles dealt round-robin, the scene
+// replicated, the tiles gathered to the first GPU over RCCL (rt_render_frame_multi_host).  Everything else - single
+// rays, timing passes, multi-sample frames - stays on the first GPU.
+static int gpu_count() {
+    const char* env = std::getenv("RT_GPUS");
+    const int n = env ? std::atoi(env) : 1;
+    return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
+// One context per scene and GPU: a context holds one uploaded scene at a time.
 struct GpuScene {
     rt_scene* scene = nullptr;
-    rt_ctx* ctx = nullptr;
+    rt_ctx* ctx = nullptr;                       // the first GPU
+    std::vector<rt_ctx*> all;                    // RT_GPUS > 1: every GPU's context, all[0] == ctx
+    std::vector<rt_comm*> comms;
     GpuScene() = default;
     GpuScene(const GpuScene&) = delete;
     GpuScene& operator=(const GpuScene&) = delete;
     ~GpuScene() {
+        for (rt_comm* c : comms) if (c) rt_comm_destroy(c);
+        for (size_t k = 1; k < all.size(); ++k) if (all[k]) rt_ctx_destroy(all[k]);
         if (ctx) rt_ctx_destroy(ctx);
         if (scene) rt_scene_destroy(scene);
     }
@@ -42,6 +55,20 @@ struct GpuScene {
         if (ctx) return;
         if (int rc = rt_ctx_create(device_index(), &ctx)) { ctx = nullptr; gpu_fail("no GPU context", rc); }
         if (int rc = rt_scene_upload(ctx, scene)) gpu_fail("scene upload", rc);
+    }
+    // contexts on the other GPUs and the group over all of them, on first use
+    void spread(int n) {
+        if (!comms.empty() || n < 2) return;
+        upload();
+        all.assign(1, ctx);
+        for (int k = 1; k < n; ++k) {
+            rt_ctx* c = nullptr;
+            if (int rc = rt_ctx_create(device_index() + k, &c)) gpu_fail("RT_GPUS: no context on a further GPU", rc);
+            all.push_back(c);
+            if (int rc = rt_scene_upload(c, scene)) gpu_fail("scene upload", rc);
+        }
+        comms.assign(n, nullptr);
+        if (int rc = rt_comm_create_all(all.data(), n, comms.data())) { comms.clear(); gpu_fail("RT_GPUS: no RCCL group", rc); }
     }
 };
 
@@ -764,7 +791,12 @@ bool RayTracer::render_to_image(const std::string& camera_id, Image& out, int sa
     if (m_light_order.empty() || m_scene_mesh_ptrs.empty()) return true;
     GpuScene& g = gpu();
     std::vector<unsigned char> rgb(static_cast<size_t>(c.width) * static_cast<size_t>(c.height) * 3);
-    if (int rc = rt_render_samples_host(g.ctx, &c, samples_per_pixel, m_sample_seed, max_scatters, min_scatter_intensity, rgb.data()))
+    const int n_gpus = samples_per_pixel == 1 ? rt_host::gpu_count() : 1;
+    if (n_gpus > 1) {
+        g.spread(n_gpus);
+        if (int rc = rt_render_frame_multi_host(g.comms.data(), n_gpus, &c, 64, max_scatters < 0 ? 0 : max_scatters, min_scatter_intensity, rgb.data()))
+            rt_host::gpu_fail("render on several GPUs", rc);
+    } else if (int rc = rt_render_samples_host(g.ctx, &c, samples_per_pixel, m_sample_seed, max_scatters, min_scatter_intensity, rgb.data()))
         rt_host::gpu_fail("render", rc);
     out.assign_rgb(rgb.data());
     return true;

@@ -80,8 +80,8 @@ struct rt_ctx {
         if (hipEvent_t e = timing_event(2 * ev_kind.size() - 1)) (void)hipEventRecord(e, stream);
     }
     // grow-only scratch of the *_host conveniences
-    void* scratch[7] = {};    // 0..2 host conveniences, 3 frame working set, 4 one sample's colours, 5 sample sums, 6 bounce levels
-    size_t scratch_bytes[7] = {};
+    void* scratch[8] = {};    // 0..2 host conveniences, 3 frame working set, 4 one sample's colours, 5 sample sums, 6 bounce levels, 7 gathered tiles
+    size_t scratch_bytes[8] = {};
 
     void free_scene() {
         if (d_nodes) (void)hipFree(d_nodes);
@@ -109,6 +109,12 @@ struct rt_ctx {
         return RT_OK;
     }
 };
+
+// for rt_comm.cpp
+int rt_fail(int code, const std::string& msg) { return fail(code, msg); }
+hipStream_t rt_ctx_stream(rt_ctx* ctx) { return ctx->stream; }
+int rt_ctx_device(rt_ctx* ctx) { return ctx->device; }
+int rt_ctx_scratch(rt_ctx* ctx, int slot, size_t bytes, void** out) { return ctx->need(slot, bytes, out); }   // slots 0..2 and 7
 
 namespace {
 
@@ -1185,6 +1191,7 @@ const char* rt_strerror(int status) {
         case RT_ERR_NO_SCENE: return "no scene uploaded";
         case RT_ERR_LIMIT: return "limit exceeded";
         case RT_ERR_PARSE: return "malformed number in scene file";
+        case RT_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }

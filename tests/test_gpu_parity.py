@@ -254,6 +254,53 @@ def test_tiles_and_subrectangles(ctx):
     assert np.array_equal(sid.cpu().numpy().reshape(h, w), ids[y0:y0 + h, x0:x0 + w])
 
 
+def test_gather_tiles_through_rccl_with_one_rank(ctx):
+    """rt_gather_tiles is what a multi-GPU host calls per frame.  One GPU can only be a group of one: that still binds
+    RCCL, creates a communicator, copies rank 0's own tiles and scatters them into the frame - the frame must be the
+    single launch's.  Arguments that do not fit the communicator are refused."""
+    import torch
+    prims, lights, camd = S.random_scene(60, 15, lights=2)
+    W, H = 328, 200
+    cam = capi.make_camera(**dict(camd, res=(W, H)))
+    ctx.upload(capi.Scene.create(prims, lights))
+    full = ctx.render(cam, max_scatters=0)
+    comm = capi.Comm(ctx, 1, 0, capi.comm_unique_id())
+    tiling = capi.Tiling(W, H, 64, 1)
+    local = torch.empty(capi.tiles_per_rank(tiling) * 64 * 64 * 3, dtype=torch.uint8, device="cuda")
+    frame = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        ctx.render_tiles_dev(cam, tiling, 0, local.data_ptr(), 0, 0.0)
+        comm.gather_tiles(tiling, local.data_ptr(), frame.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), full)
+    with pytest.raises(capi.RtError) as e:
+        comm.gather_tiles(capi.Tiling(W, H, 64, 2), local.data_ptr(), frame.data_ptr())     # two ranks asked of a group of one
+    assert e.value.status == -1
+    with pytest.raises(capi.RtError):
+        comm.gather_tiles(tiling, local.data_ptr(), None)                                    # rank 0 without a frame
+    with pytest.raises(capi.RtError):
+        capi.Comm(ctx, 2, 2, capi.comm_unique_id())                                          # rank outside the group
+    comm.close()
+    # the form for one process that drives several GPUs, with the one GPU there is
+    import ctypes as C
+    ctxs = (C.c_void_p * 1)(ctx.h)
+    comms = (C.c_void_p * 1)()
+    assert capi.lib().rt_comm_create_all(ctxs, 1, comms) == 0
+    bufs = (C.c_void_p * 1)(local.data_ptr())
+    frame.zero_()
+    assert capi.lib().rt_gather_tiles_all(comms, 1, tiling, bufs, frame.data_ptr()) == 0
+    ctx.synchronize()
+    assert np.array_equal(frame.cpu().numpy().reshape(H, W, 3), full)
+    # ... and the whole frame for a host-memory caller (what the C++ mirror calls under RT_GPUS)
+    host = np.zeros((H, W, 3), dtype=np.uint8)
+    assert capi.lib().rt_render_frame_multi_host(comms, 1, C.byref(cam), 64, 0, 0.0, host.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(host, full)
+    twice = (C.c_void_p * 2)(ctx.h, ctx.h)
+    two = (C.c_void_p * 2)()
+    assert capi.lib().rt_comm_create_all(twice, 2, two) == -1                                # one GPU cannot be two ranks
+    assert capi.lib().rt_comm_destroy(comms[0]) == 0
+
+
 def test_callers_stream_and_device_pointers(ctx):
     import torch
     prims, lights, camd = S.random_scene(30, 8, lights=1)
