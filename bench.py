@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak
-L1_PATH_PEAK_GBS = 64 * 256 * 2.4          # bytes per clock and CU x CUs x GHz
 NODE_BYTES, PRIM_BYTES = 32, 64
+WIDE_NODE_BYTES = 4 * NODE_BYTES           # a step of the walk fetches one wide node: four boxes
 # algorithmic flops: a slab test (6 sub, 6 mul, 12 min/max, 6 compares), a primitive test by kind (cube / cylinder: two
 # 3x3 matrix-vector products and slabs or a quadratic; ellipsoid; plane / triangle)
 NODE_FLOPS = 30
@@ -47,9 +47,29 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(scene, prims, lights, camd, budget_s, threads):
+def mean_sd(xs):
+    xs = [float(x) for x in xs]
+    m = sum(xs) / len(xs)
+    return m, (sum((x - m) ** 2 for x in xs) / (len(xs) - 1)) ** 0.5 if len(xs) > 1 else 0.0
+
+
+# The real reference, unmodified, g++ -O2, one thread (it has none), ray loop only, primary rays, `time_driver <scene>
+# <camera> 3` in the development container (8-vCPU Xeon): the reference does not travel to the GPU box, so these are
+# quoted, not re-measured.  Mrays/s, seconds +- sigma over 3 trials.
+CPU_REFERENCE_SURVEY = {
+    "what": "unmodified reference (s2899221/Code, tests/raytracer/time_driver.cpp), g++ 11.4 -O2, 1 thread, primary rays only, "
+            "measured in the development container (8-vCPU Intel Xeon), 3 trials each",
+    "Test2_141_prims_129600_rays": {"brute_force_Mrays_s": 0.050, "brute_force_s": [2.581, 0.021], "bvh_Mrays_s": 0.386, "bvh_s": [0.336, 0.006]},
+    "200_rand_200_prims_230400_rays": {"brute_force_Mrays_s": 0.129, "brute_force_s": [1.785, 0.146], "bvh_Mrays_s": 0.355, "bvh_s": [0.649, 0.018]},
+    "Test1_21_prims": {"brute_force_Mrays_s": 1.08, "bvh_Mrays_s": 0.81},
+    "toy_4_prims": {"brute_force_Mrays_s": 1.96, "bvh_Mrays_s": 0.76},
+}
+
+
+def cpu_baseline(scene, prims, lights, camd, budget_s, threads, trials=3):
     """The CPU restatement (oracle, "port") walking the same flattened BVH on a strided pixel sample of the same
-    frame, all requested host threads (OpenMP over rows).  Returns the bench JSON object and the sampled counts."""
+    frame, all requested host threads (OpenMP over rows); every leg `trials` times, mean and sigma as the reference's
+    timing driver reports them (tests/raytracer/time_driver.cpp:11-22).  Returns the bench JSON object."""
     from oracle import bind
     O = bind.Oracle()
     osc = O.scene(prims, lights)
@@ -58,43 +78,55 @@ def cpu_baseline(scene, prims, lights, camd, budget_s, threads):
     cam = bind.camera_from_dict(O, camd)
     W, H = camd["res"]
     threads = threads or min(os.cpu_count() or 1, 16)
-    # calibrate on a coarse grid, then pick the stride that fills the budget
+    # calibrate on a coarse grid, then pick the stride that fills a third of the budget per trial
     t0 = time.perf_counter()
     _, _, counts, hits = O.bvh_render(osc, bvh, cam, step=16, threads=threads)
     dt = time.perf_counter() - t0
     n_cal = ((W + 15) // 16) * ((H + 15) // 16)
     per_px = dt / max(n_cal, 1)
-    step = max(1, int(np.ceil(np.sqrt(W * H * per_px / max(budget_s, 1e-3)))))
-    t0 = time.perf_counter()
-    _, _, counts, hits = O.bvh_render(osc, bvh, cam, step=step, threads=threads)
-    dt = time.perf_counter() - t0
+    step = max(1, int(np.round(np.sqrt(W * H * per_px * trials / max(0.6 * budget_s, 1e-3)))))
     n_px = ((W + step - 1) // step) * ((H + step - 1) // step)
+    times = []
+    for _ in range(trials):
+        t0 = time.perf_counter()
+        _, _, counts, hits = O.bvh_render(osc, bvh, cam, step=step, threads=threads)
+        times.append(time.perf_counter() - t0)
     rays = n_px + hits * len(lights)
+    dt, dt_sd = mean_sd(times)
     # the same walk on one thread, and the reference's own algorithm (every primitive against every ray, strict '<') on
-    # one thread: a few seconds each, on coarser samples of the same frame
-    step1 = max(step, int(np.ceil(np.sqrt(W * H * per_px * threads / 3.0))))
-    t0 = time.perf_counter()
-    _, _, _, hits1 = O.bvh_render(osc, bvh, cam, step=step1, threads=1)
-    dt1 = time.perf_counter() - t0
+    # one thread: about a second per trial each, on coarser samples of the same frame
+    step1 = max(step, int(np.ceil(np.sqrt(W * H * per_px * threads * trials / max(0.2 * budget_s, 1e-3)))))
+    times1 = []
+    for _ in range(trials):
+        t0 = time.perf_counter()
+        _, _, _, hits1 = O.bvh_render(osc, bvh, cam, step=step1, threads=1)
+        times1.append(time.perf_counter() - t0)
+    dt1, dt1_sd = mean_sd(times1)
     rays1 = ((W + step1 - 1) // step1) * ((H + step1 - 1) // step1) + hits1 * len(lights)
-    n_brute = max(4, int(3.0 / (150e-9 * max(len(prims), 1))))
+    n_brute = max(4, int(0.2 * budget_s / trials / (150e-9 * max(len(prims), 1))))
     rng = np.random.default_rng(1)
     pix = np.stack([rng.integers(0, W, n_brute) + 0.5, rng.integers(0, H, n_brute) + 0.5], axis=1)
     brute_rays = O.pixel_rays(cam, pix)
-    t0 = time.perf_counter()
-    O.trace_rays(osc, brute_rays, threads=1)
-    dtb = time.perf_counter() - t0
+    timesb = []
+    for _ in range(trials):
+        t0 = time.perf_counter()
+        O.trace_rays(osc, brute_rays, threads=1)
+        timesb.append(time.perf_counter() - t0)
+    dtb, dtb_sd = mean_sd(timesb)
     return {
-        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "single_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "sample": "every %dth pixel, %d rays, %.1f s" % (step1, rays1, dt1)},
-        "brute_force_single_thread": {"value": n_brute / dtb / 1e6, "unit": "Mrays/s",
-                                      "sample": "%d primary rays against all %d primitives (the reference's one_pass_intersection), %.1f s"
-                                                % (n_brute, len(prims), dtb)},
-        "sample": "every %dth pixel in x and y of the same frame (%d primary + %d shadow rays, %.1f s), "
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "trials": trials,
+        "seconds_mean": dt, "seconds_sd": dt_sd,
+        "single_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "trials": trials, "seconds_mean": dt1, "seconds_sd": dt1_sd,
+                          "sample": "every %dth pixel, %d rays" % (step1, rays1)},
+        "brute_force_single_thread": {"value": n_brute / dtb / 1e6, "unit": "Mrays/s", "trials": trials, "seconds_mean": dtb, "seconds_sd": dtb_sd,
+                                      "sample": "%d primary rays against all %d primitives (the reference's one_pass_intersection)"
+                                                % (n_brute, len(prims))},
+        "sample": "every %dth pixel in x and y of the same frame (%d primary + %d shadow rays, %.1f s per trial), "
                   "FP64 C restatement through the same flattened BVH, OpenMP x%d, CPU: %s"
                   % (step, n_px, hits * len(lights), dt, threads, cpu_model()),
         "nodes_per_primary_ray": counts[0] / max(n_px, 1), "prims_per_primary_ray": counts[1] / max(n_px, 1),
         "nodes_per_shadow_ray": counts[2] / max(hits * len(lights), 1), "prims_per_shadow_ray": counts[3] / max(hits * len(lights), 1),
+        "cpu_reference_survey": CPU_REFERENCE_SURVEY,
     }
 
 
@@ -111,7 +143,7 @@ def main():
     ap.add_argument("--device-build", action="store_true", help="build the hierarchy on the GPU (Morton order, top-down split)")
     ap.add_argument("--instanced", action="store_true",
                     help="the two-level workload instead: one 10 008-triangle mesh placed --n-side x --n-side times (100 -> 100 M triangles)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 disables it)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -218,19 +250,33 @@ def main():
     bytes_primary = NODE_BYTES * c["nodes_primary"] + PRIM_BYTES * c["prims_primary"] + 8 * c["primary_rays"]
     bytes_shadow = NODE_BYTES * c["nodes_shadow"] + PRIM_BYTES * c["prims_shadow"] + 9 * c["shadow_rays"]
 
+    # what the vector-memory path of this GPU can deliver with the walk's own load sequence and nothing behind it (a few
+    # milliseconds, untimed): every lane its own node of an L1-resident table / one node per wave / plain streaming
+    probe = None
+    if rank == 0:
+        probe = {"node_per_lane_l1": max(ctx.probe_fetch_rate(0, 16 << 10, 4096) for _ in range(3)),
+                 "node_per_lane_l2": max(ctx.probe_fetch_rate(0, 16 << 20, 2048) for _ in range(3)),
+                 "node_per_wave_l1": max(ctx.probe_fetch_rate(1, 16 << 10, 4096) for _ in range(3)),
+                 "stream_hbm_16B_loads": max(ctx.probe_fetch_rate(2, 1 << 30, 2048) for _ in range(3))}
+
     for _ in range(args.warmup):
         step()
     fence()
     ctx.set_timing(True)          # HIP events around every launch, on the stream the kernels run on
     ctx.timing()
+    # one more pair of events per step, on the same stream, for the spread over the steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record(stream)
+    for k in range(args.steps):
         step()
+        marks[k + 1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
     tm = ctx.timing()
     ctx.set_timing(False)
-    # the shadow pass dominates (about 80 % of the frame): one launch per batch of up to 8 lights and per bounce level
+    # the shadow pass dominates (about 70 % of the frame): one launch per batch of up to 8 lights and per bounce level
     wide = args.device_build or scene.n_wide() > 0
     kname, k_ms, k_bytes = "k_rays<1,false,0,%s,%s> (shadow pass)" % ("true" if args.instanced else "false", "true" if wide else "false"), tm["shadow_ms"] / max(tm["shadow_launches"], 1), \
         bytes_shadow / max(tm["shadow_launches"] // args.steps, 1)
@@ -246,13 +292,20 @@ def main():
     if rank == 0:
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         # HBM-side bytes per launch of the same kernel on the same workload, from committed rocprofv3 PMC passes
-        # (profiles/make_traffic.py); null when no measurement matches this run
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
-        if world == 1 and args.max_scatters == 0 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj["workload"]["n_side"] == args.n_side and tj["workload"]["rays_per_frame"] == rays_per_frame:
-                traffic = tj["traffic_bytes_per_launch"]
+        # (profiles/make_traffic.py; counters cannot be read from inside this process); null when no measurement
+        # matches this run's workload
+        traffic, traffic_src = None, None
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        for name in sorted((f for f in os.listdir(pdir) if f.endswith("_traffic.json")), reverse=True):
+            tj = json.load(open(os.path.join(pdir, name)))
+            if (world == 1 and args.max_scatters == 0 and tj["workload"]["n_side"] == args.n_side
+                    and tj["workload"]["rays_per_frame"] == rays_per_frame and tj.get("res", "3840x2160") == "%dx%d" % (W, H)
+                    and tj.get("algorithmic_bytes_per_launch") == k_bytes):
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + name
+                break
+        # the ceiling of the walk's node fetches: wide nodes per second with every lane on its own L1-resident node
+        node_peak = probe["node_per_lane_l1"] * WIDE_NODE_BYTES / 1e9
+        ms_mean, ms_sd = mean_sd(step_ms)
         frame_bytes = bytes_primary + bytes_shadow
         device_ms = sum(stage_ms.values())
         out = {
@@ -282,19 +335,29 @@ def main():
                              else ("binned SAH on the host: one tree over the instances, one per mesh" if args.instanced else "binned SAH, built on the host"),
                 "arithmetic": "FP32 padded-box traversal through 4-wide nodes, FP64 leaf tests and shading",
             },
+            "ms_per_step_device": {"mean": ms_mean, "sd": ms_sd, "min": min(step_ms), "max": max(step_ms), "n": len(step_ms),
+                                   "what": "HIP events around each step on the kernels' stream (rank 0)"},
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                # what actually crossed the fabric, per second: the algorithmic figure above counts every node and record a
-                # ray fetches, and most of those fetches are served by L1 / L2, so it can exceed the HBM peak
-                "hbm_side_achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None,
-                "hbm_side_frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                # Bound: the vector-memory request path (texture addresser -> L1), which every node fetch of the walk takes
+                # and which the counters show four fifths busy (profiles/: TA_BUSY), not HBM: most fetches hit L1 / L2.
+                # achieved = ALGORITHMIC bytes of the dominant launch (32 B per box tested, 64 B per primitive record, 9 B per
+                # shadow ray) / its duration from HIP events; peak = the same load sequence measured in this run with
+                # nothing behind it (rt_probe_fetch_rate: every lane its own 128-byte node, table resident in L1).
+                "bound": "l1", "achieved": achieved, "peak": node_peak, "unit": "GB/s", "frac": achieved / node_peak,
+                "peak_source": "measured in this run: rt_probe_fetch_rate(pattern 0, 16 KiB table) x 128 B per wide node",
+                "traffic": traffic, "traffic_source": traffic_src,
+                # the same launch against HBM itself: what crossed the fabric (PMC counters) per second
+                "hbm": {"achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                        # not a fraction of anything: algorithmic bytes count every fetch, and most are served by caches
+                        "algorithmic_over_peak": achieved / HBM_PEAK_GBS},
                 # the secondary bound: algorithmic flops of the same launch against the FP32 vector peak
                 "fp32": {"achieved": k_flops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": k_flops / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": k_flops},
-                # the path every load takes into a CU's L1 (texture addresser): 64 bytes per clock and CU (the CDNA3 figure,
-                # assumed unchanged), 256 CUs at 2.4 GHz - the counters show this path about four fifths busy
-                "l1_path": {"achieved": achieved, "peak": L1_PATH_PEAK_GBS, "unit": "GB/s", "frac": achieved / L1_PATH_PEAK_GBS},
+                "probe_GBps": {"node_per_lane_l1": probe["node_per_lane_l1"] * WIDE_NODE_BYTES / 1e9,
+                               "node_per_lane_l2": probe["node_per_lane_l2"] * WIDE_NODE_BYTES / 1e9,
+                               "node_per_wave_l1": probe["node_per_wave_l1"] * WIDE_NODE_BYTES / 1e9,
+                               "stream_hbm": probe["stream_hbm_16B_loads"] * 16 / 1e9},
                 # what a frame must read and write at least once: every node and record, 3 bytes per pixel
                 "compulsory_bytes_per_frame": NODE_BYTES * int(info.n_nodes) + PRIM_BYTES * int(info.n_slots + info.n_loose) + 3 * W * H,
                 "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,

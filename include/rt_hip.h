@@ -307,6 +307,14 @@ int rt_ctx_set_counting(rt_ctx* ctx, int on);
  * differ (the counting kernels then include the boxes the search itself fetched).  The reference has no counterpart
  * (its traversal starts every ray at the root, raytracer.cpp:501-512). */
 int rt_ctx_set_entry_search(rt_ctx* ctx, int on);
+/* Measurement helper with no counterpart in the reference: the rate at which this GPU delivers 128-byte wide nodes to
+ * lanes when the walk's load sequence (seven 16-byte loads per lane and node) runs with nothing behind it, in the ray
+ * kernels' launch shape.  pattern 0: every lane its own node of a table of table_bytes (a power of two; 16 KiB sits in a
+ * CU's L1, a few MiB in L2); pattern 1: the lanes of a wave share the node; pattern 2: plain streaming of 16-byte loads
+ * over table_bytes.  per_second_out = nodes (pattern 2: 16-byte loads) per second over all lanes.  bench.py prices the
+ * dominant kernel's node fetches against pattern 0 on an L1-resident table.  Uses the context's host-convenience
+ * scratch; synchronises. */
+int rt_probe_fetch_rate(rt_ctx* ctx, int pattern, uint64_t table_bytes, uint32_t steps, double* per_second_out);
 
 /* Convenience for host-memory callers (the C++ host mirror): whole-frame render / trace into host buffers.
  * These allocate device scratch inside the context and synchronise. */

@@ -22,7 +22,7 @@ ARCH = "gfx950"
 # RT_EXTRA_FLAGS: extra compiler flags for experiments (e.g. -DRT_RAYS_MIN_WAVES=5 -DRT_STACK_LDS=12)
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"] + os.environ.get("RT_EXTRA_FLAGS", "").split()
-DEVICE_SOURCES = ["rt_kernels.hip", "rt_gpu_build.hip"]
+DEVICE_SOURCES = ["rt_kernels.hip", "rt_gpu_build.hip", "rt_probe.hip"]
 HOST_SOURCES = ["rt_capi.cpp", "rt_comm.cpp", "rt_scene.cpp", "rt_prep.cpp", "rt_bvh.cpp", "rt_json.cpp", "rt_image.cpp"]
 
 

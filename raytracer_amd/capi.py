@@ -11,7 +11,8 @@ import numpy as np
 from .scenes import INSTANCE_DT, LIGHT_DT, PRIM_DT
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "librt_hip.so")
+# RT_HIP_LIB: another build of the library (experiments with compile-time variants, profiles/variant.py)
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(HERE, "lib", "librt_hip.so")
 
 NODE_DT = np.dtype([("lo", "<f4", (3,)), ("first", "<u4"), ("hi", "<f4", (3,)), ("count", "<u4")])
 NODE4_DT = np.dtype([("lo", "<f4", (3, 4)), ("hi", "<f4", (3, 4)), ("ref", "<u4", (4,)), ("pad", "<u4", (4,))])   # rt_node4
@@ -128,6 +129,7 @@ SYMBOLS = [
     ("rt_ctx_set_counting", C.c_int, [_VP, C.c_int]),
     ("rt_ctx_set_timing", C.c_int, [_VP, C.c_int]),
     ("rt_ctx_set_entry_search", C.c_int, [_VP, C.c_int]),
+    ("rt_probe_fetch_rate", C.c_int, [_VP, C.c_int, _U64, _U32, C.POINTER(C.c_double)]),
     ("rt_timing_read", C.c_int, [_VP, C.POINTER(Timing)]),
     ("rt_render_frame_host", C.c_int, [_VP, C.POINTER(Camera), C.c_int, _D, _VP, _VP]),
     ("rt_trace_primary_host", C.c_int, [_VP, C.POINTER(Camera), _VP, _VP]),
@@ -419,6 +421,13 @@ class Context:
     def set_entry_search(self, on):
         """Start each tile's walks at the deepest node its beam of rays must pass through (default on)."""
         _check(lib().rt_ctx_set_entry_search(self.h, 1 if on else 0))
+
+    def probe_fetch_rate(self, pattern=0, table_bytes=16384, steps=4096):
+        """Nodes (pattern 2: 16-byte loads) per second the GPU delivers to lanes with the walk's load sequence and nothing
+        else: pattern 0 every lane its own node of the table, 1 one node per wave, 2 streaming."""
+        out = C.c_double(0.0)
+        _check(lib().rt_probe_fetch_rate(self.h, int(pattern), int(table_bytes), int(steps), C.byref(out)))
+        return out.value
 
     def set_timing(self, on):
         _check(lib().rt_ctx_set_timing(self.h, 1 if on else 0))

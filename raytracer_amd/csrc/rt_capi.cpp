@@ -115,6 +115,7 @@ int rt_fail(int code, const std::string& msg) { return fail(code, msg); }
 hipStream_t rt_ctx_stream(rt_ctx* ctx) { return ctx->stream; }
 int rt_ctx_device(rt_ctx* ctx) { return ctx->device; }
 int rt_ctx_scratch(rt_ctx* ctx, int slot, size_t bytes, void** out) { return ctx->need(slot, bytes, out); }   // slots 0..2 and 7
+uint32_t rt_ctx_max_waves(rt_ctx* ctx) { return ctx->max_waves; }                                              // rt_probe.hip
 
 namespace {
 
