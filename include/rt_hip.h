@@ -307,6 +307,12 @@ int rt_ctx_set_counting(rt_ctx* ctx, int on);
  * differ (the counting kernels then include the boxes the search itself fetched).  The reference has no counterpart
  * (its traversal starts every ray at the root, raytracer.cpp:501-512). */
 int rt_ctx_set_entry_search(rt_ctx* ctx, int on);
+/* When on, the closest-hit entry points (rt_trace_primary, rt_trace_rays, rt_trace_rays_full and their _host forms) run
+ * RayTracer::one_pass_intersection as the reference does (raytracer.cpp:143-157): every primitive against every ray, no
+ * hierarchy - the loop time_trace_all_one_pass times (raytracer.cpp:553-565).  Results equal the hierarchy's (ids,
+ * distances, records bit for bit); cost is O(rays x primitives), meant for scenes of a few thousand primitives.  Off by
+ * default.  Instanced scenes: RT_ERR_INVALID.  The render entry points are not affected. */
+int rt_ctx_set_brute_force(rt_ctx* ctx, int on);
 /* Measurement helper with no counterpart in the reference: the rate at which this GPU delivers 128-byte wide nodes to
  * lanes when the walk's load sequence (seven 16-byte loads per lane and node) runs with nothing behind it, in the ray
  * kernels' launch shape.  pattern 0: every lane its own node of a table of table_bytes (a power of two; 16 KiB sits in a

@@ -129,6 +129,7 @@ SYMBOLS = [
     ("rt_ctx_set_counting", C.c_int, [_VP, C.c_int]),
     ("rt_ctx_set_timing", C.c_int, [_VP, C.c_int]),
     ("rt_ctx_set_entry_search", C.c_int, [_VP, C.c_int]),
+    ("rt_ctx_set_brute_force", C.c_int, [_VP, C.c_int]),
     ("rt_probe_fetch_rate", C.c_int, [_VP, C.c_int, _U64, _U32, C.POINTER(C.c_double)]),
     ("rt_timing_read", C.c_int, [_VP, C.POINTER(Timing)]),
     ("rt_render_frame_host", C.c_int, [_VP, C.POINTER(Camera), C.c_int, _D, _VP, _VP]),
@@ -421,6 +422,10 @@ class Context:
     def set_entry_search(self, on):
         """Start each tile's walks at the deepest node its beam of rays must pass through (default on)."""
         _check(lib().rt_ctx_set_entry_search(self.h, 1 if on else 0))
+
+    def set_brute_force(self, on):
+        """Closest-hit entry points test every primitive against every ray (the reference's one_pass_intersection)."""
+        _check(lib().rt_ctx_set_brute_force(self.h, 1 if on else 0))
 
     def probe_fetch_rate(self, pattern=0, table_bytes=16384, steps=4096):
         """Nodes (pattern 2: 16-byte loads) per second the GPU delivers to lanes with the walk's load sequence and nothing

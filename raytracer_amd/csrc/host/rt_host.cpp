@@ -18,6 +18,17 @@
 
 namespace rt_host {
 
+// Scenes up to this size keep the reference's every-primitive loop behind RayTracer::one_pass_intersection.
+constexpr size_t kBruteForceMaxPrims = 4096;
+// Brute-force mode of a context for the lifetime of the object (rt_ctx_set_brute_force).
+struct BruteForce {
+    rt_ctx* ctx; bool on;
+    BruteForce(rt_ctx* c, bool enable) : ctx(c), on(enable) { if (on) rt_ctx_set_brute_force(ctx, 1); }
+    ~BruteForce() { if (on) rt_ctx_set_brute_force(ctx, 0); }
+    BruteForce(const BruteForce&) = delete;
+    BruteForce& operator=(const BruteForce&) = delete;
+};
+
 [[noreturn]] static void gpu_fail(const char* what, int rc) {
     throw std::runtime_error(std::string(what) + ": " + rt_strerror(rc) + " (" + rt_last_error() + ")");
 }
@@ -719,6 +730,9 @@ std::vector<Hit> RayTracer::one_pass_intersection(const std::vector<Ray>& rays) 
     GpuScene& g = gpu();
     std::vector<double> packed, rec(rays.size() * 16);
     rt_host::pack_rays(rays, packed);
+    // the reference's one_pass_intersection is the loop over all primitives (raytracer.cpp:143-157); so is this one while
+    // the scene is small enough for that to be cheap - beyond, the hierarchy gives the same hits
+    rt_host::BruteForce mode(g.ctx, m_scene_mesh_ptrs.size() <= rt_host::kBruteForceMaxPrims);
     if (int rc = rt_trace_rays_full_host(g.ctx, packed.data(), rays.size(), rec.data())) rt_host::gpu_fail("one_pass_intersection", rc);
     for (size_t i = 0; i < rays.size(); ++i) {
         const double* r = &rec[i * 16];
@@ -765,7 +779,7 @@ Pixel RayTracer::shade(const Hit& hit, const Ray& view_ray) const {
     return shade(std::vector<Hit>{ hit }, std::vector<Ray>{ view_ray })[0];
 }
 
-bool RayTracer::trace_primary(const std::string& camera_id, std::vector<int>& hit_index, std::vector<double>& distance) const {
+bool RayTracer::trace_primary(const std::string& camera_id, std::vector<int>& hit_index, std::vector<double>& distance, bool brute_force) const {
     auto it = m_cameras.find(camera_id);
     if (it == m_cameras.end()) return false;
     const rt_camera& c = it->second.raw();
@@ -775,6 +789,7 @@ bool RayTracer::trace_primary(const std::string& camera_id, std::vector<int>& hi
     if (m_scene_mesh_ptrs.empty()) return true;
     GpuScene& g = gpu();
     static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
+    rt_host::BruteForce mode(g.ctx, brute_force);
     if (int rc = rt_trace_primary_host(g.ctx, &c, hit_index.data(), distance.data())) rt_host::gpu_fail("trace_primary", rc);
     return true;
 }
@@ -813,22 +828,22 @@ bool RayTracer::render_unaccelerated_ppm(const std::string& camera_id, const std
 
 // ---- free functions ----------------------------------------------------------------------------------------------------------
 
-// raytracer.cpp:553-585.  Both time one closest-hit pass over all primary rays with the rays and the scene already
-// resident on the device, as the reference times only its intersection loop.  Both run the same GPU traversal: the
-// brute-force loop of the reference has no counterpart here.
-static double time_one_pass(const std::string& json_filepath, const std::string& camera_id) {
+// raytracer.cpp:553-585.  Both time one closest-hit pass over all primary rays with the scene already resident on the
+// device, as the reference times only its intersection loop: the first with every primitive tested against every ray
+// (raytracer.cpp:553-565), the second through the hierarchy (raytracer.cpp:567-585).
+static double time_one_pass(const std::string& json_filepath, const std::string& camera_id, bool brute_force) {
     RayTracer rt;
     if (!rt.load_from_json(json_filepath)) return 0.0;
     std::vector<int> ids; std::vector<double> dist;
-    if (!rt.trace_primary(camera_id, ids, dist)) return 0.0;          // first call: upload, allocation, warm-up
+    if (!rt.trace_primary(camera_id, ids, dist, brute_force)) return 0.0;          // first call: upload, allocation, warm-up
     const auto t0 = std::chrono::high_resolution_clock::now();
-    rt.trace_primary(camera_id, ids, dist);
+    rt.trace_primary(camera_id, ids, dist, brute_force);
     const auto t1 = std::chrono::high_resolution_clock::now();
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
-double time_trace_all_one_pass(const std::string& json_filepath, const std::string& camera_id) { return time_one_pass(json_filepath, camera_id); }
-double time_trace_all_accelerated_one_pass(const std::string& json_filepath, const std::string& camera_id) { return time_one_pass(json_filepath, camera_id); }
+double time_trace_all_one_pass(const std::string& json_filepath, const std::string& camera_id) { return time_one_pass(json_filepath, camera_id, true); }
+double time_trace_all_accelerated_one_pass(const std::string& json_filepath, const std::string& camera_id) { return time_one_pass(json_filepath, camera_id, false); }
 
 // raytracer.cpp:454-499 re-designed: the hierarchy is the library's flattened SAH tree; node_store receives one
 // BoundingBox per internal node (N - 1 of them for N bounded objects with one object per leaf).

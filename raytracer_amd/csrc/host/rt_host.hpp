@@ -313,7 +313,9 @@ public:
     // reference draws its sub-pixel offsets from std::random_device)
     std::vector<Hit> one_pass_intersection(const std::vector<Ray>& rays) const;
     std::vector<Pixel> shade(const std::vector<Hit>& hits, const std::vector<Ray>& view_rays) const;
-    bool trace_primary(const std::string& camera_id, std::vector<int>& hit_index, std::vector<double>& distance) const;
+    // brute_force: every primitive against every ray on the device, as the reference's one_pass_intersection does
+    // (raytracer.cpp:143-157), instead of the walk through the hierarchy; same ids and distances either way
+    bool trace_primary(const std::string& camera_id, std::vector<int>& hit_index, std::vector<double>& distance, bool brute_force = false) const;
     void set_scene(std::vector<Cube> cubes, std::vector<Plane> planes, std::vector<Cylinder> cylinders, std::vector<Sphere> spheres,
                    std::vector<Triangle> triangles, const std::vector<PointLight>& lights);
     void add_camera(const std::string& id, const Camera& cam) { m_cameras[id] = cam; }

@@ -63,6 +63,7 @@ struct rt_ctx {
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
     int refill_min = RT_REFILL_MIN;
     bool entry_search = true;              // start a tile's walks below the root where its beam allows (rt_ctx_set_entry_search)
+    bool brute_force = false;              // closest-hit entry points test every primitive against every ray (rt_ctx_set_brute_force)
     // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -485,6 +486,11 @@ int rt_ctx_set_entry_search(rt_ctx* ctx, int on) {
     ctx->entry_search = on != 0; return RT_OK;
 }
 
+int rt_ctx_set_brute_force(rt_ctx* ctx, int on) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->brute_force = on != 0; return RT_OK;
+}
+
 int rt_counters_reset(rt_ctx* ctx) {
     if (int rc = use(ctx)) return rc;
     RT_HIP(hipMemsetAsync(ctx->d_ctr, 0, kCounterBytes, ctx->stream));
@@ -834,6 +840,18 @@ int run_shadow_mask(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     return RT_OK;
 }
 
+// The reference's own closest-hit loop (raytracer.cpp:143-157) on the device: no hierarchy involved.
+int brute_ok(rt_ctx* ctx) {
+    if (ctx->sc.inst) return fail(RT_ERR_INVALID, "brute force is not available for instanced scenes");
+    return RT_OK;
+}
+int brute_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit_id_dev, double* dist_dev, double* records16_dev) {
+    if (int rc = brute_ok(ctx)) return rc;
+    DevCamera dc{}; PixelMap pm{};
+    RT_HIP(rt_launch_brute(ctx->stream, &ctx->sc, &dc, &pm, rays6_dev, n, ctx->counting, hit_id_dev, dist_dev, records16_dev, ctx->d_ctr));
+    return RT_OK;
+}
+
 int run_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32_t n_waves, size_t n_out,
                  uint8_t* rgb_dev, int32_t* hit_id_dev) {
     const uint32_t n_lights = ctx->sc.n_lights;
@@ -850,6 +868,12 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
     PixelMap pm; uint32_t nw = 0;
     if (int rc = rect_map(cam, rect, pm, nw)) return rc;
     DevCamera dc; to_dev_camera(*cam, dc);
+    if (ctx->brute_force) {
+        if (int rc = brute_ok(ctx)) return rc;
+        RT_HIP(rt_launch_brute(ctx->stream, &ctx->sc, &dc, &pm, nullptr, static_cast<uint64_t>(rect.w) * rect.h, ctx->counting,
+                               hit_id_dev, dist_dev, nullptr, ctx->d_ctr));
+        return RT_OK;
+    }
     QueueBlock qb(ctx->d_queue);
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, qb, &q)) return rc;
@@ -862,6 +886,7 @@ int rt_trace_rays(rt_ctx* ctx, const double* rays6_dev, uint64_t n, int32_t* hit
     if (int rc = need_scene(ctx)) return rc;
     if (n && !rays6_dev) return fail(RT_ERR_INVALID, "null rays");
     if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    if (ctx->brute_force) return brute_rays(ctx, rays6_dev, n, hit_id_dev, dist_dev, nullptr);
     RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, hit_id_dev, dist_dev, nullptr, nullptr, ctx->d_ctr));
     return RT_OK;
 }
@@ -878,6 +903,7 @@ int rt_trace_rays_full(rt_ctx* ctx, const double* rays6_dev, uint64_t n, double*
     if (int rc = need_scene(ctx)) return rc;
     if (n && (!rays6_dev || !records16_dev)) return fail(RT_ERR_INVALID, "null argument");
     if (n > 0x0FFFFFFFull * 64) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    if (ctx->brute_force) return brute_rays(ctx, rays6_dev, n, nullptr, nullptr, records16_dev);
     RT_HIP(rt_launch_trace_rays(ctx->stream, &ctx->sc, rays6_dev, n, ctx->counting, 0, nullptr, nullptr, nullptr, records16_dev, ctx->d_ctr));
     return RT_OK;
 }

@@ -107,6 +107,9 @@ hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera
 hipError_t rt_launch_verdict_mask(hipStream_t st, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr);
+// Every primitive against every ray (no hierarchy); rays = null: the camera rays of the rectangle in pm, row-major.
+hipError_t rt_launch_brute(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const double* rays, uint64_t n,
+                           int counting, int32_t* ids, double* dist, double* records, rt_counters* ctr);
 hipError_t rt_launch_accumulate(hipStream_t st, const uint8_t* rgb, uint32_t* acc, size_t n, int first);
 hipError_t rt_launch_finish_samples(hipStream_t st, const uint32_t* acc, size_t n, int spp, const uint8_t* gamma, uint8_t* rgb);
 hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec* rec, const double* rays, uint64_t n, double* records);

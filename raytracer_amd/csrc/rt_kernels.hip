@@ -1266,6 +1266,58 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene sc, const double* __
     }
 }
 
+// RayTracer::one_pass_intersection as the reference runs it (raytracer.cpp:143-157): every primitive against every ray,
+// no hierarchy.  The loop index is the same for all lanes, so a record is fetched once per wave and every lane runs the
+// same intersector; records sit in leaf order, not id order, so equal distances are resolved to the lowest id explicitly
+// (the reference's strict '<' over ascending ids).  rays = null: ray i is the camera ray of pixel i of the rectangle in pm
+// (row-major).  Same outputs as k_trace_rays.
+__global__ void __launch_bounds__(256) k_brute_rays(DevScene sc, DevCamera cam, PixelMap pm, const double* __restrict__ rays, uint64_t n,
+                                                    int32_t* __restrict__ ids, double* __restrict__ dist, double* __restrict__ records,
+                                                    int counting, rt_counters* ctr) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    bool hit = false;
+    uint32_t vp = 0;
+    if (i < n) {
+        RayD r;
+        if (rays) {
+            r.ox = rays[i*6]; r.oy = rays[i*6 + 1]; r.oz = rays[i*6 + 2];
+            r.dx = rays[i*6 + 3]; r.dy = rays[i*6 + 4]; r.dz = rays[i*6 + 5];
+            r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
+        } else {
+            primary_ray(cam, pm.x0 + static_cast<int>(i % static_cast<uint64_t>(pm.w)), pm.y0 + static_cast<int>(i / static_cast<uint64_t>(pm.w)), r);
+        }
+        Best b; b.dist = __builtin_inf(); b.slot = 0xFFFFFFFFu; b.id = -1; b.inst = REF_NONE;
+        const uint32_t n_recs = sc.n_slots + sc.n_loose;
+        for (uint32_t s = 0; s < n_recs; ++s) {
+            const rt_prim_rec* rec = sc.recs + s;
+            const uint32_t kind = rec->kind;
+            const int32_t id = static_cast<int32_t>(rec->id);
+            HitD h;
+            ++vp;
+            if (!hit_record<false>(rec, kind, r, h)) continue;
+            if (h.dist < b.dist || (h.dist == b.dist && id < b.id)) { b.dist = h.dist; b.slot = s; b.id = id; }
+        }
+        hit = b.id >= 0;
+        if (ids) ids[i] = b.id;
+        if (dist) dist[i] = b.dist;
+        if (records) {
+            double* o = records + i * 16;
+            HitD h; h.u = 0.0; h.v = 0.0;
+            int32_t mat_id;
+            if (hit) best_record<true, false>(sc, b, r, h, mat_id);
+            o[0] = hit ? 1.0 : 0.0; o[1] = static_cast<double>(b.id); o[2] = b.dist;
+            o[3] = hit ? h.px : 0.0; o[4] = hit ? h.py : 0.0; o[5] = hit ? h.pz : 0.0;
+            o[6] = hit ? h.nx : 0.0; o[7] = hit ? h.ny : 0.0; o[8] = hit ? h.nz : 0.0;
+            o[9] = hit ? h.rx : 0.0; o[10] = hit ? h.ry : 0.0; o[11] = hit ? h.rz : 0.0;
+            o[12] = hit ? h.u : 0.0; o[13] = hit ? h.v : 0.0; o[14] = 0.0; o[15] = 0.0;
+        }
+    }
+    const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
+    add_counter(ctr, shard, F_PRIMARY, i < n ? 1 : 0);
+    add_counter(ctr, shard, F_HITS, hit ? 1 : 0);
+    if (counting) add_counter(ctr, shard, F_VP_P, vp);
+}
+
 // Mesh::intersect of one primitive for n rays (mesh.cpp:159, 371, 597, 795): the record layout of k_trace_rays with the
 // primitive id slot holding 0.
 __global__ void __launch_bounds__(64) k_intersect_one(const rt_prim_rec* __restrict__ rec, const double* __restrict__ rays, uint64_t n,
@@ -1557,6 +1609,13 @@ extern "C" hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, c
     if (sc->inst) { if (sc->nodes4) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
     else          { if (sc->nodes4) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
 #undef RT_LAUNCH_TRACE
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_brute(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const double* rays, uint64_t n,
+                                      int counting, int32_t* ids, double* dist, double* records, rt_counters* ctr) {
+    const uint32_t nb = static_cast<uint32_t>((n + 255) / 256);
+    if (nb) hipLaunchKernelGGL(k_brute_rays, dim3(nb), dim3(256), 0, st, *sc, *cam, *pm, rays, n, ids, dist, records, counting, ctr);
     return hipGetLastError();
 }
 

@@ -44,6 +44,36 @@ def test_shipped_scenes_ids_and_distances(ctx, name, cam_id):
         assert np.array_equal(bits(dist[::4]), bits(g["dist_rows"]))
 
 
+@pytest.mark.parametrize("name,cam_id", SHIPPED)
+def test_brute_force_equals_the_hierarchy(ctx, name, cam_id):
+    """rt_ctx_set_brute_force: the reference's own loop over every primitive (raytracer.cpp:143-157) on the device gives the
+    reference's ids and distances, and the same hit records as the walk through the hierarchy, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "shipped_%s.npz" % name))
+    sc = capi.Scene.load_json(os.path.join(SCENES, name + ".json"))
+    cam, _ = sc.camera(cam_id)
+    ctx.upload(sc)
+    rays = g["sec_rays"] if "sec_rays" in g else None
+    rec_tree = ctx.trace_rays_full(rays) if rays is not None else None
+    try:
+        ctx.set_brute_force(True)
+        ctx.set_counting(True)
+        ctx.reset_counters()
+        ids, dist = ctx.trace_primary(cam)
+        c = ctx.counters()
+        assert np.array_equal(ids, g["ids"].astype(np.int32))
+        assert np.array_equal(bits(dist[::4]), bits(g["dist_rows"]))
+        # every primitive against every ray, nothing skipped
+        assert c["primary_rays"] == cam.width * cam.height and c["prims_primary"] == cam.width * cam.height * sc.info().n_prims
+        assert c["nodes_primary"] == 0
+        if rays is not None:
+            ids2, dist2 = ctx.trace_rays(rays)
+            assert np.array_equal(ids2, g["sec_ids"].astype(np.int32)) and np.array_equal(bits(dist2), bits(g["sec_dist"]))
+            assert np.array_equal(bits(ctx.trace_rays_full(rays)), bits(rec_tree))
+    finally:
+        ctx.set_counting(False)
+        ctx.set_brute_force(False)
+
+
 @pytest.mark.parametrize("name,cam_id", [s for s in SHIPPED])
 def test_shipped_scenes_renders(ctx, name, cam_id):
     g = np.load(os.path.join(GOLDEN, "shipped_%s.npz" % name))
