@@ -703,13 +703,13 @@ size_t frame_bytes(size_t n, uint32_t n_batch) {
     (void)n_batch;
     return n * (kFramePlanes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + RT_LIGHT_BATCH) + 256;
 }
-// Per-tile planes of the entry search: 4 + 4 * RT_LIGHT_BATCH bytes of references and 24 of box per tile.
-static_assert(RT_TILE_BYTES >= sizeof(uint32_t) * (1 + RT_LIGHT_BATCH) + 6 * sizeof(float), "tile planes");
-size_t tile_bytes(size_t n_tiles) { return n_tiles * RT_TILE_BYTES + 256; }
+// Per-tile planes of the entry search: the box of the tile's hits, one entry node for its camera rays and one per light of
+// a batch for its shadow rays.
+size_t tile_bytes(size_t n_tiles, uint32_t n_batch) { return n_tiles * RT_TILE_BYTES(n_batch) + 256; }
 void carve_tiles(void* base, size_t n_tiles, FrameBufs& fb) {
-    fb.entry_p = static_cast<uint32_t*>(base);
-    fb.entry_s = fb.entry_p + n_tiles;
-    fb.tile_box = reinterpret_cast<float*>(fb.entry_s + n_tiles * RT_LIGHT_BATCH);
+    fb.tile_box = static_cast<float*>(base);
+    fb.entry_p = reinterpret_cast<float4*>(fb.tile_box + n_tiles * 8u);
+    fb.entry_s = fb.entry_p + n_tiles * 8u;
 }
 void carve_frame(void* base, size_t n, bool textures, FrameBufs& fb) {
     fb.entry_p = nullptr; fb.entry_s = nullptr; fb.tile_box = nullptr;
@@ -730,7 +730,7 @@ int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, size_t n_tiles, FrameBuf
     void* base = nullptr;
     const size_t fbytes = (frame_bytes(n, n_batch) + 255u) & ~static_cast<size_t>(255);
     const bool entry = wants_entry_search(ctx);
-    if (int rc = ctx->need(3, fbytes + (entry ? tile_bytes(n_tiles) : 0), &base)) return rc;
+    if (int rc = ctx->need(3, fbytes + (entry ? tile_bytes(n_tiles, n_batch) : 0), &base)) return rc;
     carve_frame(base, n, ctx->sc.n_textures != 0, fb);
     if (entry) carve_tiles(static_cast<uint8_t*>(base) + fbytes, n_tiles, fb);
     return RT_OK;
@@ -1030,7 +1030,7 @@ int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8
     FrameBufs fb;
     carve_frame(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes, n_out, ctx->sc.n_textures != 0, fb);
     const size_t fbytes = (frame_bytes(n_out, batch) + 255u) & ~static_cast<size_t>(255);
-    if (wants_entry_search(ctx) && queue_bytes + fbytes + tile_bytes(nw) <= ctx->static_scratch_bytes)
+    if (wants_entry_search(ctx) && queue_bytes + fbytes + tile_bytes(nw, batch) <= ctx->static_scratch_bytes)
         carve_tiles(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes + fbytes, nw, fb);
     return run_pipeline_on(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev, fb, static_cast<unsigned int*>(ctx->static_scratch));
 }

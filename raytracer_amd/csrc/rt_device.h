@@ -17,11 +17,14 @@
 #define RT_QUEUE_PARTS 8u          // work-queue heads per launch: one per XCD
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
 #define RT_REFILL_MIN 40           // finished lanes that must pile up before a wave swaps rays (default)
-#define RT_TILE_BYTES 64u                                             // per 8x8 tile: entry references (4 + 4 * RT_LIGHT_BATCH) and the box of its hits (24)
-// workspace of rt_render_rect_static: 80 bytes per pixel, the queue heads, and the per-tile planes of up to
-// RT_STATIC_MAX_PIXELS / 16 tiles (a rectangle is covered by whole 128 x 128 blocks of tiles, so it can count four times
-// the tiles its pixels fill; beyond that the call goes without the entry search)
-#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * 80u + 4096u + (RT_STATIC_MAX_PIXELS / 16u) * RT_TILE_BYTES)
+// per 8x8 tile: one 128-byte entry node for its camera rays, one per light of a batch for its shadow rays, and the box of
+// its hits (24 bytes, padded to 32)
+#define RT_ENTRY_NODE_BYTES 128u
+#define RT_TILE_BYTES(n_batch) (RT_ENTRY_NODE_BYTES * (1u + (n_batch)) + 32u)
+// workspace of rt_render_rect_static: 80 bytes per pixel, the queue heads, and 4 MiB for per-tile planes (a call whose
+// tiles need more goes without the entry search; results are the same either way)
+#define RT_STATIC_TILE_BYTES (4u << 20)
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * 80u + 4096u + RT_STATIC_TILE_BYTES)
 
 struct DevScene {
     const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
@@ -74,11 +77,12 @@ struct FrameBufs {
     uint8_t *alive;                // levels >= 1: this slot still carries a ray
     int level;
     uint32_t *albedo;              // scenes with textures only: albedo under the hit, r | g << 8 | b << 16
-    // Entry search (wide, one-level scenes; null otherwise): where the walks of a tile's 64 rays may start instead of
-    // at the root - the deepest node that every ray of the tile's beam has to pass through.
-    uint32_t *entry_p;             // [tiles] camera rays of the tile
-    uint32_t *entry_s;             // [tiles][RT_LIGHT_BATCH] shadow rays of the tile towards one light
-    float    *tile_box;            // [tiles][6] min xyz, max xyz of the tile's hit points (min > max: no hit)
+    // Entry search (wide, one-level scenes; null otherwise): where the walks of a tile's 64 rays start instead of at the
+    // root - a wide node made for the tile's beam, whose up to four children are the subtrees the beam can touch at all
+    // (layout of a wide node: six planes of box coordinates, four references, all ones = empty place).
+    float4   *entry_p;             // [tiles][8] camera rays of the tile
+    float4   *entry_s;             // [tiles][lights of the batch][8] shadow rays of the tile towards one light
+    float    *tile_box;            // [tiles][8] min xyz, max xyz of the tile's hit points (min > max: no hit), 2 unused
 };
 
 // Per-level results of a mirror-bounce frame, folded into the final colour at the end.

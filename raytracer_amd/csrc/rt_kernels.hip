@@ -436,9 +436,9 @@ struct Walker {
     }
 
     // Root box test; afterwards cur is the first node reference or REF_NONE.
-    // entry: REF_ROOT, or where the walk may start instead - a node every ray of the tile's beam must pass through
-    // (k_entry), REF_NONE when the beam misses the whole tree.
-    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, uint32_t entry = REF_ROOT) {
+    // entry: null, or the entry node of the ray's tile (k_entry): a wide node made for the tile's beam of rays, whose up to
+    // four children are the subtrees the beam can touch at all.  The walk then starts with a step on that node.
+    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, const float4* entry = nullptr) {
         r = ray;
         if (INST) { rw = ray; inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
@@ -448,7 +448,7 @@ struct Walker {
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
-        if (WIDE && entry != REF_ROOT) { cur = entry; return; }
+        if (WIDE && !INST && entry) { step_wide<true>(entry); return; }
         if (WIDE) {
             // the root's box travels with the kernel arguments, with the wide node that holds the root's children
             if (COUNT) vn += 1;
@@ -464,33 +464,37 @@ struct Walker {
     DEV bool at_internal() const { return ref_internal(cur); }
     DEV bool done() const { return cur == REF_NONE; }
 
-    // One internal node: fetch both children (64 contiguous bytes), test, descend into the nearer, postpone the other.
-    DEV void step_internal(const DevScene& sc) {
-        if (WIDE) {
-            // One wide node: 128 contiguous bytes, four boxes.  The children that the ray enters are put in order of their
-            // entry distance (a five-exchange sorting network); the walk goes on in the nearest, the others wait on the
-            // stack, farthest pushed first.  An empty place is told by its reference (the slab test orders a box's
-            // planes itself, so an inverted box does not read as a miss).
-            const float4* n4 = sc.nodes4 + 8u * static_cast<size_t>(cur);
-            const float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5], rf = n4[6];
-            if (COUNT) vn += 4;
-            float t0 = box_entry(make_float4(lox.x, loy.x, loz.x, 0.0f), make_float4(hix.x, hiy.x, hiz.x, 0.0f), br, limit_f);
-            float t1 = box_entry(make_float4(lox.y, loy.y, loz.y, 0.0f), make_float4(hix.y, hiy.y, hiz.y, 0.0f), br, limit_f);
-            float t2 = box_entry(make_float4(lox.z, loy.z, loz.z, 0.0f), make_float4(hix.z, hiy.z, hiz.z, 0.0f), br, limit_f);
-            float t3 = box_entry(make_float4(lox.w, loy.w, loz.w, 0.0f), make_float4(hix.w, hiy.w, hiz.w, 0.0f), br, limit_f);
-            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
-            t2 = (r2 == REF_NONE) ? __builtin_inff() : t2;
-            t3 = (r3 == REF_NONE) ? __builtin_inff() : t3;
+    // One wide node: 128 contiguous bytes, four boxes.  The children that the ray enters are put in order of their
+    // entry distance (a five-exchange sorting network); the walk goes on in the nearest, the others wait on the
+    // stack, farthest pushed first.  An empty place is told by its reference (the slab test orders a box's planes itself,
+    // so an inverted box does not read as a miss); only a tile's entry node (ENTRY) can have its first two places empty.
+    template <bool ENTRY> DEV void step_wide(const float4* n4) {
+        const float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5], rf = n4[6];
+        if (COUNT) vn += 4;
+        float t0 = box_entry(make_float4(lox.x, loy.x, loz.x, 0.0f), make_float4(hix.x, hiy.x, hiz.x, 0.0f), br, limit_f);
+        float t1 = box_entry(make_float4(lox.y, loy.y, loz.y, 0.0f), make_float4(hix.y, hiy.y, hiz.y, 0.0f), br, limit_f);
+        float t2 = box_entry(make_float4(lox.z, loy.z, loz.z, 0.0f), make_float4(hix.z, hiy.z, hiz.z, 0.0f), br, limit_f);
+        float t3 = box_entry(make_float4(lox.w, loy.w, loz.w, 0.0f), make_float4(hix.w, hiy.w, hiz.w, 0.0f), br, limit_f);
+        uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+        if (ENTRY) {
+            t0 = (r0 == REF_NONE) ? __builtin_inff() : t0;
+            t1 = (r1 == REF_NONE) ? __builtin_inff() : t1;
+        }
+        t2 = (r2 == REF_NONE) ? __builtin_inff() : t2;
+        t3 = (r3 == REF_NONE) ? __builtin_inff() : t3;
 #define RT_EXCHANGE(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; \
                                       const uint32_t rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
-            RT_EXCHANGE(t0, r0, t1, r1) RT_EXCHANGE(t2, r2, t3, r3) RT_EXCHANGE(t0, r0, t2, r2) RT_EXCHANGE(t1, r1, t3, r3) RT_EXCHANGE(t1, r1, t2, r2)
+        RT_EXCHANGE(t0, r0, t1, r1) RT_EXCHANGE(t2, r2, t3, r3) RT_EXCHANGE(t0, r0, t2, r2) RT_EXCHANGE(t1, r1, t3, r3) RT_EXCHANGE(t1, r1, t2, r2)
 #undef RT_EXCHANGE
-            if (t3 != __builtin_inff()) st.push(r3, t3);
-            if (t2 != __builtin_inff()) st.push(r2, t2);
-            if (t1 != __builtin_inff()) st.push(r1, t1);
-            cur = (t0 != __builtin_inff()) ? r0 : st.pop(limit_f);
-            return;
-        }
+        if (t3 != __builtin_inff()) st.push(r3, t3);
+        if (t2 != __builtin_inff()) st.push(r2, t2);
+        if (t1 != __builtin_inff()) st.push(r1, t1);
+        cur = (t0 != __builtin_inff()) ? r0 : st.pop(limit_f);
+    }
+
+    // One internal node: fetch both children (64 contiguous bytes), test, descend into the nearer, postpone the other.
+    DEV void step_internal(const DevScene& sc) {
+        if (WIDE) { step_wide<false>(sc.nodes4 + 8u * static_cast<size_t>(cur)); return; }
         const float4* pair = reinterpret_cast<const float4*>(sc.nodes) + 4u * static_cast<size_t>(cur);
         const float4 llo = pair[0], lhi = pair[1], rlo = pair[2], rhi = pair[3];
         if (COUNT) vn += 2;
@@ -893,7 +897,25 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     ridx = rank < take_a ? q_next + rank : b_next + (rank - take_a);
                     const uint32_t g = ridx >> 6;
                     const Pixel p = map_pixel(pm, MODE == 0 ? g : g / n_batch, ridx & 63u);
-                    if (p.valid) {
+                    if (MODE == 1) {
+                        // Everything the new ray needs is asked for at once and unconditionally (slot 0 stands in where the
+                        // lane has no pixel): asking for the surface record only after the id has arrived would put two
+                        // trips to memory one behind the other in every swap.
+                        const uint32_t o = p.valid ? p.out : 0u;
+                        int32_t hid = fb.id[o];
+                        const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
+                        const float4* entry = (WIDE && !INST && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
+                        const rt_light L = sc.lights[light0 + g % n_batch];
+                        asm volatile("" : "+v"(hid));                           // the loads stay up here
+                        RayD r;
+                        const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r);
+                        if (p.valid && hid >= 0) {
+                            out = o;
+                            w.start(sc, r, deep.e, ld, entry);
+                            ++n_cast;
+                            state = w.done() ? DONE : TRAV;
+                        }
+                    } else if (p.valid) {
                         out = p.out;
                         if (MODE == 0) {
                             RayD r;
@@ -909,19 +931,11 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                 primary_ray(cam, p.x, p.y, r);
                             }
                             if (have) {
-                                const uint32_t entry = (WIDE && !INST && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p[g] : REF_ROOT;
+                                const float4* entry = (WIDE && !INST && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p + 8u * static_cast<size_t>(g) : nullptr;
                                 w.start(sc, r, deep.e, 0.0, entry);
                                 ++n_cast;
                                 state = w.done() ? DONE : TRAV;
                             }
-                        } else if (fb.id[out] >= 0) {
-                            const rt_light L = sc.lights[light0 + g % n_batch];
-                            RayD r;
-                            const double ld = shadow_ray(L, fb.px[out], fb.py[out], fb.pz[out], fb.nx[out], fb.ny[out], fb.nz[out], r);
-                            const uint32_t entry = (WIDE && !INST && fb.entry_s) ? fb.entry_s[static_cast<size_t>(g / n_batch) * RT_LIGHT_BATCH + g % n_batch] : REF_ROOT;
-                            w.start(sc, r, deep.e, ld, entry);
-                            ++n_cast;
-                            state = w.done() ? DONE : TRAV;
                         }
                     }
                 }
@@ -1060,17 +1074,18 @@ __global__ void __launch_bounds__(256) k_surface(DevScene sc, DevCamera cam, Pix
                 bhi[k] = fmaxf(bhi[k], __shfl_xor(bhi[k], off, 64));
             }
         if ((threadIdx.x & 63u) == 0) {
-            float* t = fb.tile_box + static_cast<size_t>(g) * 6u;
+            float* t = fb.tile_box + static_cast<size_t>(g) * 8u;
             t[0] = blo[0]; t[1] = blo[1]; t[2] = blo[2]; t[3] = bhi[0]; t[4] = bhi[1]; t[5] = bhi[2];
         }
     }
 }
 
 // ---- entry search ------------------------------------------------------------------------------------
-// The 64 rays of a tile form a narrow beam, and near the root they all take the same turns.  One lane per beam walks
-// the wide nodes from the root for as long as the beam can touch only ONE child of the node, and leaves the reference
-// where that ends; the tile's rays then start there.  A child is passed over only when NO ray of the beam can touch
-// its box, so nothing a ray could hit is lost and results do not change; the tests are FP64 and conservative.
+// The 64 rays of a tile form a narrow beam, and near the root they all take the same turns.  One lane per beam refines a
+// set of up to four subtrees, starting from the root: it replaces a subtree by those of its children that the beam can
+// touch, for as long as the set still fits in four places, and leaves the set as one wide node - the tile's entry node -
+// from which the tile's rays start their walks.  A child is passed over only when NO ray of the beam can touch its box,
+// so nothing a ray could hit is lost and results do not change; the tests are FP64 and conservative.
 
 // Camera rays of a tile: common origin o, directions within [wlo, whi] per axis (not normalised: a box test does not
 // depend on the direction's length when the ray has no far limit).  Interval arithmetic on the slab test.
@@ -1121,7 +1136,7 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
         // 1e-4 their origins are nudged off the surface (raytracer.cpp:221-225)
         double pad = 1e-7 * static_cast<double>(sc.radius);
         if (shadow) {
-            const float* t = fb.tile_box + static_cast<size_t>(tile) * 6u;
+            const float* t = fb.tile_box + static_cast<size_t>(tile) * 8u;
             for (int k = 0; k < 3; ++k) { o_lo[k] = t[k]; o_hi[k] = t[3 + k]; }
             any = o_lo[0] <= o_hi[0];
             const rt_light Lt = sc.lights[light0 + b % n_batch];
@@ -1148,28 +1163,74 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
             const double lo[3] = { lx - pad, ly - pad, lz - pad }, hi[3] = { hx + pad, hy + pad, hz + pad };
             return shadow ? beam_touches_shadow(o_lo, o_hi, L, lo, hi) : beam_touches_primary(o_lo, d_lo, d_hi, lo, hi);
         };
-        uint32_t node = REF_NONE;
+        // the set: four places, each a reference and its box (REF_NONE = empty place); `closed` marks places whose
+        // subtree cannot be refined at present because its touched children would not fit
+        uint32_t ref[4] = { REF_NONE, REF_NONE, REF_NONE, REF_NONE };
+        float blo[4][3] = {}, bhi[4][3] = {};
+        uint32_t closed = 0;
         if (any) {
             vn += 1;
-            if (touches(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2], sc.root_hi[0], sc.root_hi[1], sc.root_hi[2])) node = sc.root_ref;
+            if (touches(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2], sc.root_hi[0], sc.root_hi[1], sc.root_hi[2])) {
+                ref[0] = sc.root_ref;
+                for (int k = 0; k < 3; ++k) { blo[0][k] = sc.root_lo[k]; bhi[0][k] = sc.root_hi[k]; }
+            }
         }
-        // the tree is at most 31 levels deep; the bound only guards against a malformed one
-        for (int depth = 0; depth < 64 && node != REF_NONE && ref_internal(node); ++depth) {
+        // every refinement goes one level down some branch of a tree at most 31 levels deep; the bound only guards
+        // against a malformed one
+        for (int iter = 0; iter < 96; ++iter) {
+            // the widest subtree that can still be refined goes first: the set then shrinks evenly around the beam
+            int pick = -1; float widest = -1.0f; uint32_t count = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (ref[k] == REF_NONE) continue;
+                ++count;
+                if (!ref_internal(ref[k]) || ((closed >> k) & 1u)) continue;
+                const float ex = bhi[k][0] - blo[k][0], ey = bhi[k][1] - blo[k][1], ez = bhi[k][2] - blo[k][2];
+                const float size = ex * ey + ey * ez + ez * ex;
+                if (size > widest) { widest = size; pick = k; }
+            }
+            if (pick < 0) break;
+            uint32_t node = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k == pick) node = ref[k];
             const float4* n4 = sc.nodes4 + 8u * static_cast<size_t>(node);
             const float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5], rf = n4[6];
             vn += 4;
-            const uint32_t r[4] = { __float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w) };
-            const bool h[4] = { r[0] != REF_NONE && touches(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x),
-                                r[1] != REF_NONE && touches(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y),
-                                r[2] != REF_NONE && touches(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z),
-                                r[3] != REF_NONE && touches(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w) };
-            const int nh = int(h[0]) + int(h[1]) + int(h[2]) + int(h[3]);
-            if (nh == 0) { node = REF_NONE; break; }
-            if (nh > 1) break;
-            node = h[0] ? r[0] : (h[1] ? r[1] : (h[2] ? r[2] : r[3]));
+            const uint32_t cr[4] = { __float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w) };
+            const float cl[4][3] = { { lox.x, loy.x, loz.x }, { lox.y, loy.y, loz.y }, { lox.z, loy.z, loz.z }, { lox.w, loy.w, loz.w } };
+            const float ch[4][3] = { { hix.x, hiy.x, hiz.x }, { hix.y, hiy.y, hiz.y }, { hix.z, hiy.z, hiz.z }, { hix.w, hiy.w, hiz.w } };
+            bool h[4]; uint32_t nh = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                h[c] = cr[c] != REF_NONE && touches(cl[c][0], cl[c][1], cl[c][2], ch[c][0], ch[c][1], ch[c][2]);
+                nh += h[c] ? 1u : 0u;
+            }
+            if (count - 1u + nh > 4u) { closed |= 1u << pick; continue; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k == pick) ref[k] = REF_NONE;
+            if (nh == 0) closed = 0;                              // a place came free: the others get another chance
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (!h[c]) continue;
+                int place = -1;
+#pragma unroll
+                for (int k = 3; k >= 0; --k) if (ref[k] == REF_NONE) place = k;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k == place) {
+                        ref[k] = cr[c]; closed &= ~(1u << k);
+                        for (int a = 0; a < 3; ++a) { blo[k][a] = cl[c][a]; bhi[k][a] = ch[c][a]; }
+                    }
+            }
         }
-        if (shadow) fb.entry_s[static_cast<size_t>(tile) * RT_LIGHT_BATCH + b % n_batch] = node;
-        else        fb.entry_p[tile] = node;
+        float4* out = (shadow ? fb.entry_s : fb.entry_p) + 8u * static_cast<size_t>(b);      // b = tile, or tile * n_batch + light
+        out[0] = make_float4(blo[0][0], blo[1][0], blo[2][0], blo[3][0]);
+        out[1] = make_float4(blo[0][1], blo[1][1], blo[2][1], blo[3][1]);
+        out[2] = make_float4(blo[0][2], blo[1][2], blo[2][2], blo[3][2]);
+        out[3] = make_float4(bhi[0][0], bhi[1][0], bhi[2][0], bhi[3][0]);
+        out[4] = make_float4(bhi[0][1], bhi[1][1], bhi[2][1], bhi[3][1]);
+        out[5] = make_float4(bhi[0][2], bhi[1][2], bhi[2][2], bhi[3][2]);
+        out[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
     }
     if (counting) add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, shadow ? F_VN_S : F_VN_P, vn);
 }
@@ -1179,8 +1240,10 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
 DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
                           double vox, double voy, double voz, double lighting) {
     const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
+    const uint2 lit8 = *reinterpret_cast<const uint2*>(fb.lit + i * RT_LIGHT_BATCH);          // the batch's verdicts in one load
+    const unsigned long long lit = static_cast<unsigned long long>(lit8.x) | static_cast<unsigned long long>(lit8.y) << 32;
     for (uint32_t j = 0; j < n_batch; ++j) {
-        if (!fb.lit[i * RT_LIGHT_BATCH + j]) continue;
+        if (!((lit >> (8u * j)) & 255u)) continue;
         const rt_light L = sc.lights[light0 + j];
         double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
         lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, vox, voy, voz);

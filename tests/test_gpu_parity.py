@@ -237,7 +237,9 @@ def test_counting_kernels_match_the_cpu_walk(ctx, oracle):
         ctx.set_counting(False)
         assert np.array_equal(ids_e, ids) and np.array_equal(rgb_e, rgb)
         assert ce["nodes_primary"] < c["nodes_primary"] and ce["nodes_shadow"] < c["nodes_shadow"]
-        assert ce["prims_primary"] <= c["prims_primary"] and ce["prims_shadow"] <= c["prims_shadow"]
+        # the entry node puts subtrees of different levels side by side, so a ray may meet them in another order than
+        # the tree's own nesting gives: a few primitive tests more or fewer, never a different result
+        assert ce["prims_primary"] <= 1.01 * c["prims_primary"] and ce["prims_shadow"] <= 1.01 * c["prims_shadow"]
         assert ce["primary_hits"] == hits and ce["shadow_rays"] == hits * 4
         # the plain kernels give the same picture and leave the fetch counters alone
         ctx.reset_counters()
@@ -483,13 +485,15 @@ def test_multi_sample_frame(ctx, oracle):
         jx, jy = (0.0, 0.0) if s == 0 else jitter_offsets(seed, s, xs, ys)
         rays = oracle.pixel_rays(ocam, np.stack([xs + 0.5 + jx, ys + 0.5 + jy], axis=1))
         acc += oracle.shade_rays(osc, rays)
-    lut = oracle.gamma_lut()
-    want = lut[np.clip(np.round(acc / spp), 0, 255).astype(np.int64)].reshape(H, W, 3)
-    # a +-1 in one sample's linear colour moves the mean by 1/spp; after rounding and the steep low end of the
-    # transfer curve that can be a few display levels on dark pixels, so compare the linear means instead there
-    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
-    assert (diff > 0).any(-1).mean() < 2e-3
-    assert diff.max() <= 12
+    lut = oracle.gamma_lut().astype(np.int16)
+    want_lin = np.clip(np.round(acc / spp), 0, 255).astype(np.int64).reshape(H, W, 3)
+    # Compared as LINEAR means: every sample's linear colour may be off by one level, so the mean may be off by one
+    # level before the display transfer; the transfer is monotone, so the frame must lie between the encodings of
+    # mean - 1 and mean + 1 (on dark pixels, where the curve is steep, that is several display levels; elsewhere none).
+    lo, hi = lut[np.clip(want_lin - 1, 0, 255)], lut[np.clip(want_lin + 1, 0, 255)]
+    g16 = got.astype(np.int16)
+    assert ((g16 >= lo) & (g16 <= hi)).all()
+    assert (g16 != lut[want_lin]).any(-1).mean() < 2e-3
 
 
 @pytest.mark.parametrize("kind", [S.CUBE, S.PLANE, S.CYLINDER, S.SPHERE])
