@@ -26,6 +26,10 @@
 #include "rt_device.h"
 
 #define DEV __device__ __forceinline__
+#ifndef RT_ENTRY_ITERS_PRIMARY       // refinement steps of a tile's entry search at most: later steps cost the search more than
+#define RT_ENTRY_ITERS_PRIMARY 24    // they save the walks (frame time at 8 / 10 / 16 / 24 / 96 steps for both kinds of beam:
+#define RT_ENTRY_ITERS_SHADOW 16     // 6.36 / 5.97 / 5.81 / 5.82 / 5.93 ms on the 1.3 M-primitive 4K frame)
+#endif
 #ifndef RT_INNER_EXIT_REL
 #define RT_INNER_EXIT_REL 4          // 0: lanes wait until every ray of the wave has left the inner nodes
 #endif
@@ -1117,16 +1121,25 @@ __global__ void __launch_bounds__(256) k_surface(DevScene sc, DevCamera cam, Pix
 // so nothing a ray could hit is lost and results do not change; the tests are FP64 and conservative.
 
 // Camera rays of a tile: common origin o, directions within [wlo, whi] per axis (not normalised: a box test does not
-// depend on the direction's length when the ray has no far limit).  Interval arithmetic on the slab test.
-DEV bool beam_touches_primary(const double o[3], const double wlo[3], const double whi[3], const double lo[3], const double hi[3]) {
+// depend on the direction's length when the ray has no far limit).  Interval arithmetic on the slab test; the reciprocals
+// of the direction bounds belong to the beam and are made once.
+struct PrimaryBeam { double o[3], i0[3], i1[3]; int sign[3]; };      // sign: +1 / -1 all directions point that way, 0 mixed
+DEV void primary_beam_init(PrimaryBeam& p, const double o[3], const double wlo[3], const double whi[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p.o[k] = o[k];
+        p.sign[k] = (wlo[k] <= 0.0 && whi[k] >= 0.0) ? 0 : (wlo[k] > 0.0 ? 1 : -1);
+        p.i0[k] = p.sign[k] ? 1.0 / wlo[k] : 0.0; p.i1[k] = p.sign[k] ? 1.0 / whi[k] : 0.0;
+    }
+}
+DEV bool beam_touches_primary(const PrimaryBeam& p, const double lo[3], const double hi[3]) {
     double tn = 0.0, tf = __builtin_inf();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (wlo[k] <= 0.0 && whi[k] >= 0.0) continue;       // some ray may run along this slab: no constraint from it
-        const double i0 = 1.0 / wlo[k], i1 = 1.0 / whi[k];
+        if (p.sign[k] == 0) continue;                       // some ray may run along this slab: no constraint from it
         // entry through the face the directions point away from, exit through the other one
-        const double a = (wlo[k] > 0.0 ? lo[k] : hi[k]) - o[k], b = (wlo[k] > 0.0 ? hi[k] : lo[k]) - o[k];
-        const double near_lb = fmin(a * i0, a * i1), far_ub = fmax(b * i0, b * i1);
+        const double a = (p.sign[k] > 0 ? lo[k] : hi[k]) - p.o[k], b = (p.sign[k] > 0 ? hi[k] : lo[k]) - p.o[k];
+        const double near_lb = fmin(a * p.i0[k], a * p.i1[k]), far_ub = fmax(b * p.i0[k], b * p.i1[k]);
         tn = fmax(tn, near_lb); tf = fmin(tf, far_ub);
     }
     return tn <= tf + 1e-9 * fmax(1.0, tf);
@@ -1135,26 +1148,39 @@ DEV bool beam_touches_primary(const double o[3], const double wlo[3], const doub
 // Shadow rays of a tile towards one light: origins within [olo, ohi], all aiming at L.  At parameter t in [0, 1] the rays
 // are inside (1 - t) [olo, ohi] + t L; the box can be touched only if that slice overlaps it for some t, which is six
 // linear conditions on t.  (The rays' 1e-4 nudge along the normal is in the caller's padding of the box.)
-DEV bool beam_touches_shadow(const double olo[3], const double ohi[3], const double L[3], const double lo[3], const double hi[3]) {
+// The conditions' slopes belong to the beam, not to the box: b1 = L - olo, b2 = ohi - L and their reciprocals are made
+// once per beam (a product with the reciprocal is within one rounding of the quotient, far inside the slack below).
+struct ShadowBeam { double olo[3], ohi[3], b1[3], i1[3], b2[3], i2[3]; };
+DEV void shadow_beam_init(ShadowBeam& s, const double olo[3], const double ohi[3], const double L[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.olo[k] = olo[k]; s.ohi[k] = ohi[k];
+        s.b1[k] = L[k] - olo[k]; s.i1[k] = s.b1[k] != 0.0 ? 1.0 / s.b1[k] : 0.0;
+        s.b2[k] = ohi[k] - L[k]; s.i2[k] = s.b2[k] != 0.0 ? 1.0 / s.b2[k] : 0.0;
+    }
+}
+DEV bool beam_touches_shadow(const ShadowBeam& s, const double lo[3], const double hi[3]) {
     double tn = 0.0, tf = 1.0;
+    bool out = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         // olo + t (L - olo) <= hi
-        { const double b = L[k] - olo[k], r = hi[k] - olo[k];
-          if (b > 0.0) tf = fmin(tf, r / b); else if (b < 0.0) tn = fmax(tn, r / b); else if (r < 0.0) return false; }
+        { const double r = hi[k] - s.olo[k], q = r * s.i1[k];
+          if (s.b1[k] > 0.0) tf = fmin(tf, q); else if (s.b1[k] < 0.0) tn = fmax(tn, q); else out = out || r < 0.0; }
         // ohi + t (L - ohi) >= lo
-        { const double b = ohi[k] - L[k], r = ohi[k] - lo[k];
-          if (b > 0.0) tf = fmin(tf, r / b); else if (b < 0.0) tn = fmax(tn, r / b); else if (r < 0.0) return false; }
+        { const double r = s.ohi[k] - lo[k], q = r * s.i2[k];
+          if (s.b2[k] > 0.0) tf = fmin(tf, q); else if (s.b2[k] < 0.0) tn = fmax(tn, q); else out = out || r < 0.0; }
     }
-    return tn <= tf + 1e-9;
+    return !out && tn <= tf + 1e-9;
 }
 
 // n_batch = 0: beams of camera rays, one per tile -> fb.entry_p.  Otherwise beams of shadow rays, one per tile and light
 // of the batch -> fb.entry_s (needs fb.tile_box from k_surface).
+template <bool SHADOW>
 __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0, uint32_t n_batch,
                                                int counting, FrameBufs fb, rt_counters* ctr) {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    const bool shadow = n_batch != 0;
+    constexpr bool shadow = SHADOW;
     const uint32_t n_beams = shadow ? n_tiles * n_batch : n_tiles;
     uint32_t vn = 0;
     if (b < n_beams) {
@@ -1188,9 +1214,12 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
             for (int k = 0; k < 3; ++k) wmax = fmax(wmax, fmax(fabs(d_lo[k]), fabs(d_hi[k])));
             for (int k = 0; k < 3; ++k) { d_lo[k] -= 1e-9 * wmax; d_hi[k] += 1e-9 * wmax; }
         }
+        ShadowBeam sb;
+        PrimaryBeam pb;
+        if (shadow) shadow_beam_init(sb, o_lo, o_hi, L); else primary_beam_init(pb, o_lo, d_lo, d_hi);
         auto touches = [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
             const double lo[3] = { lx - pad, ly - pad, lz - pad }, hi[3] = { hx + pad, hy + pad, hz + pad };
-            return shadow ? beam_touches_shadow(o_lo, o_hi, L, lo, hi) : beam_touches_primary(o_lo, d_lo, d_hi, lo, hi);
+            return shadow ? beam_touches_shadow(sb, lo, hi) : beam_touches_primary(pb, lo, hi);
         };
         // the set: four places, each a reference and its box (REF_NONE = empty place); `closed` marks places whose
         // subtree cannot be refined at present because its touched children would not fit
@@ -1204,9 +1233,7 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
                 for (int k = 0; k < 3; ++k) { blo[0][k] = sc.root_lo[k]; bhi[0][k] = sc.root_hi[k]; }
             }
         }
-        // every refinement goes one level down some branch of a tree at most 31 levels deep; the bound only guards
-        // against a malformed one
-        for (int iter = 0; iter < 96; ++iter) {
+        for (int iter = 0; iter < (SHADOW ? RT_ENTRY_ITERS_SHADOW : RT_ENTRY_ITERS_PRIMARY); ++iter) {
             // the widest subtree that can still be refined goes first: the set then shrinks evenly around the beam
             int pick = -1; float widest = -1.0f; uint32_t count = 0;
 #pragma unroll
@@ -1651,8 +1678,9 @@ extern "C" hipError_t rt_launch_entry_search(hipStream_t st, const DevScene* sc,
                                              uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb, rt_counters* ctr) {
     const uint64_t n_beams = static_cast<uint64_t>(n_tiles) * (n_batch ? n_batch : 1u);
     if (!sc->nodes4 || sc->inst || !fb || !fb->entry_p || n_beams == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_entry, dim3(static_cast<uint32_t>((n_beams + 255u) / 256u)), dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch,
-                       counting, *fb, ctr);
+    const dim3 grid(static_cast<uint32_t>((n_beams + 255u) / 256u));
+    if (n_batch) hipLaunchKernelGGL(k_entry<true>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
+    else         hipLaunchKernelGGL(k_entry<false>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
     return hipGetLastError();
 }
 
