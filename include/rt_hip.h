@@ -300,12 +300,13 @@ int rt_timing_read(rt_ctx* ctx, rt_timing* out);
  * record fetches per ray class (slower; for roofline accounting and tests). */
 int rt_ctx_set_counting(rt_ctx* ctx, int on);
 
-/* Entry search (on by default; scenes walked through wide nodes, not instanced ones): before a closest-hit or shadow
- * launch of the frame pipeline one lane per 8x8-pixel tile follows the tile's beam of rays down from the root for as long
- * as the beam can touch only one child of a node, and the tile's rays start their walks there.  A subtree is passed over
- * only when no ray of the beam can touch its box, so results are identical with it on or off; only the node counters
- * differ (the counting kernels then include the boxes the search itself fetched).  The reference has no counterpart
- * (its traversal starts every ray at the root, raytracer.cpp:501-512). */
+/* Entry search (on by default; scenes walked through wide nodes, two-level ones through their top-level tree): before a
+ * closest-hit or shadow launch of the frame pipeline one lane per 8x8-pixel tile refines, from the root down, a set of up
+ * to four subtrees that the tile's beam of rays can touch, and the tile's rays start their walks from that set (its
+ * "entry node").  A subtree is passed over only when no ray of the beam can touch its box, so results are identical with
+ * it on or off; only the node counters differ (the counting kernels then include the boxes the search itself fetched,
+ * and rays may meet subtrees in another order).  The reference has no counterpart (its traversal starts every ray at the
+ * root, raytracer.cpp:501-512). */
 int rt_ctx_set_entry_search(rt_ctx* ctx, int on);
 /* When on, the closest-hit entry points (rt_trace_primary, rt_trace_rays, rt_trace_rays_full and their _host forms) run
  * RayTracer::one_pass_intersection as the reference does (raytracer.cpp:143-157): every primitive against every ray, no

@@ -725,7 +725,7 @@ void carve_frame(void* base, size_t n, bool textures, FrameBufs& fb) {
 }
 
 // The same out of the context's grow-only scratch (allocated on first use of a size).
-bool wants_entry_search(const rt_ctx* ctx) { return ctx->entry_search && ctx->sc.nodes4 && !ctx->sc.inst; }
+bool wants_entry_search(const rt_ctx* ctx) { return ctx->entry_search && ctx->sc.nodes4; }
 int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, size_t n_tiles, FrameBufs& fb) {
     void* base = nullptr;
     const size_t fbytes = (frame_bytes(n, n_batch) + 255u) & ~static_cast<size_t>(255);
@@ -761,8 +761,13 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
     fb.alive = lv.last + n_out;
     if (pm.mode == 1) RT_HIP(hipMemsetAsync(fb.id, 0xFF, n_out * sizeof(int32_t), ctx->stream));
     QueueBlock qb(ctx->d_queue);
+    float4* const entry_s = fb.entry_s;
+    float* const tile_box = fb.tile_box;
     for (int level = 0; level <= max_scatters; ++level) {
         fb.level = level;
+        // deeper levels: a tile's hits lie all over the scene, its shadow rays are no beam; their walks start at the root
+        fb.entry_s = level == 0 ? entry_s : nullptr;
+        fb.tile_box = level == 0 ? tile_box : nullptr;
         unsigned int* q = nullptr;
         if (int rc = next_queue(ctx, qb, &q)) return rc;
         ctx->mark_begin(0);

@@ -6,7 +6,7 @@
 #include "rt_internal.h"
 
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 16            // traversal stack entries per lane kept in LDS (8 bytes each); deeper ones go private
+#define RT_STACK_LDS 12            // traversal stack entries per lane kept in LDS (8 bytes each); deeper ones go private
 #endif
 #define RT_CTR_SHARDS 64           // counter replicas, one cache line each, summed on read
 #define RT_CTR_STRIDE 16           // 64-bit words between replicas (128 bytes)
@@ -79,7 +79,7 @@ struct FrameBufs {
     uint8_t *alive;                // levels >= 1: this slot still carries a ray
     int level;
     uint32_t *albedo;              // scenes with textures only: albedo under the hit, r | g << 8 | b << 16
-    // Entry search (wide, one-level scenes; null otherwise): where the walks of a tile's 64 rays start instead of at the
+    // Entry search (scenes walked through wide nodes; null otherwise): where the walks of a tile's 64 rays start instead of at the
     // root - a wide node made for the tile's beam, whose up to four children are the subtrees the beam can touch at all
     // (layout of a wide node: six planes of box coordinates, four references, all ones = empty place).
     float4   *entry_p;             // [tiles][8] camera rays of the tile

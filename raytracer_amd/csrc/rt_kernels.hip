@@ -395,6 +395,20 @@ struct Stack {
     }
 };
 
+// Two-level scenes: while a walk is inside an instance its ray in the world waits here ([component][lane]); it is only
+// needed again when the walk leaves the instance, and fourteen registers are worth more than seven LDS reads then.
+__shared__ double g_lds_world[7 * 64];
+DEV void world_ray_park(const RayD& r) {
+    const uint32_t l = threadIdx.x & 63u;
+    g_lds_world[l] = r.ox; g_lds_world[64 + l] = r.oy; g_lds_world[128 + l] = r.oz;
+    g_lds_world[192 + l] = r.dx; g_lds_world[256 + l] = r.dy; g_lds_world[320 + l] = r.dz; g_lds_world[384 + l] = r.dlen;
+}
+DEV void world_ray_fetch(RayD& r) {
+    const uint32_t l = threadIdx.x & 63u;
+    r.ox = g_lds_world[l]; r.oy = g_lds_world[64 + l]; r.oz = g_lds_world[128 + l];
+    r.dx = g_lds_world[192 + l]; r.dy = g_lds_world[256 + l]; r.dz = g_lds_world[320 + l]; r.dlen = g_lds_world[384 + l];
+}
+
 struct Best { double dist; uint32_t slot; int32_t id; uint32_t inst; };
 
 // Two-level scenes.  A ray enters an instance as o' = rot^T (o - trans), d' = rot^T d; what it finds there comes back
@@ -434,7 +448,6 @@ DEV void hit_out_of_instance(const rt_inst_rec* in, HitD& h) {
 template <int MODE, bool COUNT, bool INST = false, bool WIDE = false>
 struct Walker {
     RayD r;                             // in the frame being walked: the world, or the current instance's
-    RayD rw;                            // INST: the ray in the world
     uint32_t inst; int32_t id_off;      // INST: instance slot being walked (REF_NONE in the top level), its id offset
     BoxRay br;
     Stack st;
@@ -473,7 +486,7 @@ struct Walker {
     // four children are the subtrees the beam can touch at all.  The walk then starts with a step on that node.
     DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, const float4* entry = nullptr) {
         r = ray;
-        if (INST) { rw = ray; inst = REF_NONE; id_off = 0; }
+        if (INST) { world_ray_park(ray); inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
         st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
@@ -481,7 +494,7 @@ struct Walker {
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
-        if (WIDE && !INST && entry) { step_wide<true>(entry); return; }
+        if (WIDE && entry) { step_wide<true>(entry); return; }
         if (WIDE) {
             // the root's box travels with the kernel arguments, with the wide node that holds the root's children
             if (COUNT) vn += 1;
@@ -547,7 +560,7 @@ struct Walker {
     DEV void step_leaf(const DevScene& sc) {
         if (INST) {
             if (cur == REF_LEAVE) {                 // the instance is exhausted: back to the world
-                r = rw; inst = REF_NONE; id_off = 0;
+                world_ray_fetch(r); inst = REF_NONE; id_off = 0;
                 box_ray_init(br, r, sc.radius);
                 cur = st.pop(limit_f);
                 return;
@@ -557,7 +570,7 @@ struct Walker {
                 const rt_inst_rec* in = sc.inst + slot;
                 const uint4 tail = *reinterpret_cast<const uint4*>(&in->root_ref);
                 st.push(REF_LEAVE, 0.0f);
-                ray_into_instance(in, rw, r);
+                { const RayD world = r; ray_into_instance(in, world, r); }      // in the top-level tree r is the world ray
                 box_ray_init(br, r, __uint_as_float(tail.z));
                 inst = slot; id_off = static_cast<int32_t>(tail.y);
                 cur = tail.x;
@@ -937,7 +950,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         const uint32_t o = p.valid ? p.out : 0u;
                         int32_t hid = fb.id[o];
                         const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
-                        const float4* entry = (WIDE && !INST && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
+                        const float4* entry = (WIDE && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
                         const rt_light L = sc.lights[light0 + g % n_batch];
                         asm volatile("" : "+v"(hid));                           // the loads stay up here
                         RayD r;
@@ -964,7 +977,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                 primary_ray(cam, p.x, p.y, r);
                             }
                             if (have) {
-                                const float4* entry = (WIDE && !INST && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p + 8u * static_cast<size_t>(g) : nullptr;
+                                const float4* entry = (WIDE && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p + 8u * static_cast<size_t>(g) : nullptr;
                                 w.start(sc, r, deep.e, 0.0, entry);
                                 ++n_cast;
                                 state = w.done() ? DONE : TRAV;
@@ -1677,7 +1690,7 @@ extern "C" hipError_t rt_launch_primary(hipStream_t st, const DevScene* sc, cons
 extern "C" hipError_t rt_launch_entry_search(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, uint32_t n_tiles,
                                              uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb, rt_counters* ctr) {
     const uint64_t n_beams = static_cast<uint64_t>(n_tiles) * (n_batch ? n_batch : 1u);
-    if (!sc->nodes4 || sc->inst || !fb || !fb->entry_p || n_beams == 0) return hipSuccess;
+    if (!sc->nodes4 || !fb || !fb->entry_p || n_beams == 0) return hipSuccess;
     const dim3 grid(static_cast<uint32_t>((n_beams + 255u) / 256u));
     if (n_batch) hipLaunchKernelGGL(k_entry<true>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
     else         hipLaunchKernelGGL(k_entry<false>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
