@@ -201,6 +201,7 @@ def main():
         ctx.upload(scene)          # the first build also loads the builder's code objects: report a build in steady state
 
     tiling = capi.Tiling(W, H, args.tile, world)
+    gather_path = "rt_gather_tiles (RCCL send / grouped recv)"
     if world == 1:
         frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
         def step():
@@ -221,11 +222,31 @@ def main():
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, src=0)
-            comm = capi.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
-            local = torch.zeros(capi.tiles_per_rank(tiling) * args.tile * args.tile * 3, dtype=torch.uint8, device="cuda")
-            def step():
-                ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
-                comm.gather_tiles(tiling, local.data_ptr(), frame.data_ptr() if rank == 0 else None)
+            comm, why = None, ""
+            try:
+                comm = capi.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+            except Exception as e:                       # e.g. RCCL not loadable under the name the library looks for
+                why = str(e)
+            # every rank must take the same road: if the group could not be formed anywhere, all fall back to the same
+            # exchange through torch.distributed (RCCL underneath as well), and the line says so
+            agreed = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                gather_path = "torch.distributed.gather (rt_comm_create failed: %s)" % (why or "on another rank")
+                from raytracer_amd import tiles
+                tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
+                def step():
+                    ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
+                    gathered = tg.gather()
+                    if rank == 0:
+                        ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+            else:
+                local = torch.zeros(capi.tiles_per_rank(tiling) * args.tile * args.tile * 3, dtype=torch.uint8, device="cuda")
+                def step():
+                    ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
+                    comm.gather_tiles(tiling, local.data_ptr(), frame.data_ptr() if rank == 0 else None)
 
     def fence():
         if dist is not None:
@@ -283,7 +304,7 @@ def main():
     by_kind = [int(v) for v in info.n_by_kind]
     prim_flops = sum(PRIM_FLOPS.get(k, 0) * n for k, n in enumerate(by_kind)) / max(sum(by_kind), 1)
     k_flops = (NODE_FLOPS * c["nodes_shadow"] + prim_flops * c["prims_shadow"]) / max(tm["shadow_launches"] // args.steps, 1)
-    stage_ms = {k: tm[k] / args.steps for k in ("primary_ms", "shadow_ms", "resolve_ms", "bounce_ms")}
+    stage_ms = {k: tm[k] / args.steps for k in ("entry_ms", "primary_ms", "shadow_ms", "resolve_ms", "bounce_ms")}
     t = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -327,7 +348,7 @@ def main():
                 "n_side": args.n_side, "n_prims": int(info.n_instanced_prims if args.instanced else info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
                 "wide_nodes": (2 * int(info.n_slots) if ctx.build_time_ms() > 0 else scene.n_wide()),
                 "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
-                "partition": ("image tiles round-robin over %d ranks, scene replicated, rt_gather_tiles (RCCL send / grouped recv) to rank 0" % world
+                "partition": ("image tiles round-robin over %d ranks, scene replicated, %s to rank 0" % (world, gather_path)
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],
                 "shadow_rays": total["shadow_rays"], "bounce_rays": total["bounce_rays"], "scene_build_s": round(build_s, 3),

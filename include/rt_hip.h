@@ -115,6 +115,8 @@ typedef struct rt_counters {
 typedef struct rt_timing {
     double   primary_ms, shadow_ms, resolve_ms, bounce_ms;        /* summed over the launches below */
     uint32_t primary_launches, shadow_launches, resolve_launches, bounce_launches;
+    double   entry_ms;                                            /* the entry searches of both ray classes, on their own */
+    uint32_t entry_launches, reserved;
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* host side: descriptions + flattened records + BVH */

@@ -18,4 +18,4 @@ for n in (1, 2, 4, 8):
     for _ in range(20):
         ctx.render_tiles_dev(cam, tiling, 0, buf.data_ptr(), 0, 0.0)
     t = ctx.timing()
-    print("ranks %d: primary %.3f shadow %.3f resolve %.3f ms per frame" % (n, t["primary_ms"] / 20, t["shadow_ms"] / 20, t["resolve_ms"] / 20), flush=True)
+    print("ranks %d: entry searches %.3f closest hits + surface %.3f shadow %.3f resolve %.3f ms per frame" % (n, t["entry_ms"] / 20, t["primary_ms"] / 20, t["shadow_ms"] / 20, t["resolve_ms"] / 20), flush=True)

@@ -70,7 +70,7 @@ class Texture(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("primary_ms", C.c_double), ("shadow_ms", C.c_double), ("resolve_ms", C.c_double), ("bounce_ms", C.c_double),
                 ("primary_launches", C.c_uint32), ("shadow_launches", C.c_uint32), ("resolve_launches", C.c_uint32),
-                ("bounce_launches", C.c_uint32)]
+                ("bounce_launches", C.c_uint32), ("entry_ms", C.c_double), ("entry_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/rt_hip.h declares: (name, restype, argtypes)

@@ -465,8 +465,8 @@ int rt_timing_read(rt_ctx* ctx, rt_timing* out) {
     if (int rc = use(ctx)) return rc;
     std::memset(out, 0, sizeof(*out));
     RT_HIP(hipStreamSynchronize(ctx->stream));
-    double* ms[4] = { &out->primary_ms, &out->shadow_ms, &out->resolve_ms, &out->bounce_ms };
-    uint32_t* n[4] = { &out->primary_launches, &out->shadow_launches, &out->resolve_launches, &out->bounce_launches };
+    double* ms[5] = { &out->primary_ms, &out->shadow_ms, &out->resolve_ms, &out->bounce_ms, &out->entry_ms };
+    uint32_t* n[5] = { &out->primary_launches, &out->shadow_launches, &out->resolve_launches, &out->bounce_launches, &out->entry_launches };
     for (size_t k = 0; k < ctx->ev_kind.size(); ++k) {
         float t = 0.0f;
         RT_HIP(hipEventElapsedTime(&t, ctx->ev_pool[2*k], ctx->ev_pool[2*k + 1]));
@@ -770,16 +770,20 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
         fb.tile_box = level == 0 ? tile_box : nullptr;
         unsigned int* q = nullptr;
         if (int rc = next_queue(ctx, qb, &q)) return rc;
-        ctx->mark_begin(0);
+        if (fb.entry_p && level == 0) ctx->mark_begin(4);
         if (fb.entry_p && level == 0) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
+        if (fb.entry_p && level == 0) ctx->mark_end();
+        ctx->mark_begin(0);
         RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting,
                                  level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill_min));
         ctx->mark_end();
         for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
             const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
             if (int rc = next_queue(ctx, qb, &q)) return rc;
-            ctx->mark_begin(1);
+            if (fb.entry_s) ctx->mark_begin(4);
             if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, l0, nb, ctx->counting, &fb, ctx->d_ctr));
+            if (fb.entry_s) ctx->mark_end();
+            ctx->mark_begin(1);
             RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                     ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
             ctx->mark_end();
@@ -806,16 +810,20 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     QueueBlock qb(queue_heads);
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, qb, &q)) return rc;
-    ctx->mark_begin(0);
+    if (fb.entry_p) ctx->mark_begin(4);
     if (fb.entry_p) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
+    if (fb.entry_p) ctx->mark_end();
+    ctx->mark_begin(0);
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
                              &fb, ctx->d_ctr, q, ctx->refill_min));
     ctx->mark_end();
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
         if (int rc = next_queue(ctx, qb, &q)) return rc;
-        ctx->mark_begin(1);
+        if (fb.entry_s) ctx->mark_begin(4);
         if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, l0, nb, ctx->counting, &fb, ctx->d_ctr));
+        if (fb.entry_s) ctx->mark_end();
+        ctx->mark_begin(1);
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
         ctx->mark_end();
