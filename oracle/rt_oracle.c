@@ -882,29 +882,32 @@ typedef struct {
     const rto_scene* sc; const rto_bvh* bvh; int64_t* counts;
 } bvh_ctx;
 
-typedef struct { float op[3], om[3], inv[3]; } box_ray;   /* origin +/- pad, reciprocal direction */
+typedef struct { float inv[3], np[3], nm[3]; } box_ray;   /* reciprocal direction, -(origin +/- pad) * reciprocal */
 
 static void box_ray_init(box_ray* br, const double o[3], const double d[3], float radius) {
-    /* padding = 2^-18 * max(|origin|, scene radius); direction normalised before the FP32 reciprocal */
+    /* padding = 2^-18 * max(|origin|, scene radius); direction normalised before the FP32 reciprocal, which is kept
+     * finite (+-2^100) so that a ray along an axis yields huge distances of the right sign */
     const float ox = (float)o[0], oy = (float)o[1], oz = (float)o[2];
     const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
     const float pad = ldexpf(m, -18);
+    const float big = 1.2676506e30f;
     const double d_len = sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
     const float of[3] = { ox, oy, oz };
     for (int k = 0; k < 3; ++k) {
-        br->op[k] = of[k] + pad;
-        br->om[k] = of[k] - pad;
-        br->inv[k] = 1.0f / (float)(d[k] / d_len);
+        br->inv[k] = fminf(fmaxf(1.0f / (float)(d[k] / d_len), -big), big);
+        br->np[k] = -(of[k] + pad) * br->inv[k];
+        br->nm[k] = -(of[k] - pad) * br->inv[k];
     }
 }
 
-/* Slab test against the box grown by pad on every side; returns the entry distance clamped to >= 0,
- * or +inf when the ray misses or the box starts beyond `limit`. */
+/* Slab test against the box grown by pad on every side, each plane's distance as one fused multiply-add (the product's
+ * arithmetic, so that both walks visit the same boxes); returns the entry distance clamped to >= 0, or +inf when the
+ * ray misses or the box starts beyond `limit`. */
 static float box_entry(const rto_node32* nd, const box_ray* br, float limit) {
     float tn = 0.0f, tf = limit;
     for (int k = 0; k < 3; ++k) {
-        const float a = (nd->lo[k] - br->op[k]) * br->inv[k];
-        const float b = (nd->hi[k] - br->om[k]) * br->inv[k];
+        const float a = fmaf(nd->lo[k], br->inv[k], br->np[k]);
+        const float b = fmaf(nd->hi[k], br->inv[k], br->nm[k]);
         const float t0 = fminf(a, b), t1 = fmaxf(a, b);
         tn = fmaxf(tn, t0);
         tf = fminf(tf, t1);

@@ -304,7 +304,12 @@ template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec
 
 // ---- BVH traversal ---------------------------------------------------------------------------
 
-struct BoxRay { float opx, opy, opz, omx, omy, omz, ix, iy, iz; };
+// What a box test needs of a ray.  A plane x = c of the padded box is crossed at t = (c - (o +- pad)) / d, evaluated as
+// one fused multiply-add c * (1/d) + (-(o +- pad) * (1/d)): ix.. are the reciprocals (clamped to +-2^100, so that a ray
+// running along an axis gives huge finite distances of the right sign instead of inf - inf), npx.. / nmx.. the
+// products -(o + pad) / d and -(o - pad) / d.  Rounding: the products carry 2^-24 of |o| / |d|, i.e. |o| 2^-24 along the
+// ray's path - a sixty-fourth of the padding (2^-18 max(|o|, scene radius)), like the other two roundings of the form.
+struct BoxRay { float ix, iy, iz, npx, npy, npz, nmx, nmy, nmz; };
 
 DEV float f32_up(double x) {                       // smallest float >= max(x, 0); NaN -> +inf
     if (!(x == x)) return __builtin_inff();
@@ -337,18 +342,19 @@ DEV void box_ray_init(BoxRay& b, const RayD& r, float radius) {
     const float ox = static_cast<float>(r.ox), oy = static_cast<float>(r.oy), oz = static_cast<float>(r.oz);
     const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
     const float pad = ldexpf(m, -RT_PAD_SHIFT);
-    b.opx = ox + pad; b.opy = oy + pad; b.opz = oz + pad;
-    b.omx = ox - pad; b.omy = oy - pad; b.omz = oz - pad;
-    b.ix = 1.0f / static_cast<float>(r.dx / r.dlen);
-    b.iy = 1.0f / static_cast<float>(r.dy / r.dlen);
-    b.iz = 1.0f / static_cast<float>(r.dz / r.dlen);
+    const float big = 1.2676506e30f;                                  // 2^100
+    b.ix = fminf(fmaxf(1.0f / static_cast<float>(r.dx / r.dlen), -big), big);
+    b.iy = fminf(fmaxf(1.0f / static_cast<float>(r.dy / r.dlen), -big), big);
+    b.iz = fminf(fmaxf(1.0f / static_cast<float>(r.dz / r.dlen), -big), big);
+    b.npx = -(ox + pad) * b.ix; b.npy = -(oy + pad) * b.iy; b.npz = -(oz + pad) * b.iz;
+    b.nmx = -(ox - pad) * b.ix; b.nmy = -(oy - pad) * b.iy; b.nmz = -(oz - pad) * b.iz;
 }
 
 // Entry distance (>= 0) into the padded box, +inf on a miss or when the box starts beyond `limit`.
 DEV float box_entry(const float4 lo, const float4 hi, const BoxRay& b, float limit) {
-    const float ax = (lo.x - b.opx) * b.ix, bx = (hi.x - b.omx) * b.ix;
-    const float ay = (lo.y - b.opy) * b.iy, by = (hi.y - b.omy) * b.iy;
-    const float az = (lo.z - b.opz) * b.iz, bz = (hi.z - b.omz) * b.iz;
+    const float ax = __builtin_fmaf(lo.x, b.ix, b.npx), bx = __builtin_fmaf(hi.x, b.ix, b.nmx);
+    const float ay = __builtin_fmaf(lo.y, b.iy, b.npy), by = __builtin_fmaf(hi.y, b.iy, b.nmy);
+    const float az = __builtin_fmaf(lo.z, b.iz, b.npz), bz = __builtin_fmaf(hi.z, b.iz, b.nmz);
     float tn = fmaxf(0.0f, fminf(ax, bx));
     float tf = fminf(limit, fmaxf(ax, bx));
     tn = fmaxf(tn, fminf(ay, by)); tf = fminf(tf, fmaxf(ay, by));
