@@ -885,7 +885,7 @@ typedef struct {
 typedef struct { float inv[3], np[3], nm[3]; } box_ray;   /* reciprocal direction, -(origin +/- pad) * reciprocal */
 
 static void box_ray_init(box_ray* br, const double o[3], const double d[3], float radius) {
-    /* padding = 2^-18 * max(|origin|, scene radius); direction normalised before the FP32 reciprocal, which is kept
+    /* padding = 2^-18 * max(|origin|, scene radius); reciprocal of the normalised direction as |d| / d in FP32, kept
      * finite (+-2^100) so that a ray along an axis yields huge distances of the right sign */
     const float ox = (float)o[0], oy = (float)o[1], oz = (float)o[2];
     const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
@@ -894,7 +894,7 @@ static void box_ray_init(box_ray* br, const double o[3], const double d[3], floa
     const double d_len = sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
     const float of[3] = { ox, oy, oz };
     for (int k = 0; k < 3; ++k) {
-        br->inv[k] = fminf(fmaxf(1.0f / (float)(d[k] / d_len), -big), big);
+        br->inv[k] = fminf(fmaxf((float)d_len / (float)d[k], -big), big);
         br->np[k] = -(of[k] + pad) * br->inv[k];
         br->nm[k] = -(of[k] - pad) * br->inv[k];
     }

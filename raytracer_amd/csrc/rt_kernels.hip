@@ -343,9 +343,10 @@ DEV void box_ray_init(BoxRay& b, const RayD& r, float radius) {
     const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
     const float pad = ldexpf(m, -RT_PAD_SHIFT);
     const float big = 1.2676506e30f;                                  // 2^100
-    b.ix = fminf(fmaxf(1.0f / static_cast<float>(r.dx / r.dlen), -big), big);
-    b.iy = fminf(fmaxf(1.0f / static_cast<float>(r.dy / r.dlen), -big), big);
-    b.iz = fminf(fmaxf(1.0f / static_cast<float>(r.dz / r.dlen), -big), big);
+    const float len = static_cast<float>(r.dlen);                     // 1 / (d / |d|) in one FP32 division per axis
+    b.ix = fminf(fmaxf(len / static_cast<float>(r.dx), -big), big);
+    b.iy = fminf(fmaxf(len / static_cast<float>(r.dy), -big), big);
+    b.iz = fminf(fmaxf(len / static_cast<float>(r.dz), -big), big);
     b.npx = -(ox + pad) * b.ix; b.npy = -(oy + pad) * b.iy; b.npz = -(oz + pad) * b.iz;
     b.nmx = -(ox - pad) * b.ix; b.nmy = -(oy - pad) * b.iy; b.nmz = -(oz - pad) * b.iz;
 }
@@ -652,15 +653,16 @@ struct ShadeCounters { uint32_t shadow_rays, vn, vp; };
 DEV double shadow_ray(const rt_light& L, double px, double py, double pz, double nx, double ny, double nz, RayD& sr) {
     const double lx = L.pos[0] - px, ly = L.pos[1] - py, lz = L.pos[2] - pz;
     const double len2 = lx*lx + ly*ly + lz*lz;
-    const double dist2 = (1e-12 < len2) ? len2 : 1e-12;
-    double dx, dy, dz; normalize3(lx, ly, lz, dx, dy, dz);
+    const double len = dsqrt(len2);                 // one root serves the direction and the light's distance
+    double dx = 0.0, dy = 0.0, dz = 1.0;            // normalize3(lx, ly, lz)
+    if (!(len <= 1e-15)) { dx = lx/len; dy = ly/len; dz = lz/len; }
     const double eps = 1e-4;
     const double ndl = nx*dx + ny*dy + nz*dz;
     const double s = (ndl >= 0.0) ? 1.0 : -1.0;
     sr.ox = px + s * nx * eps; sr.oy = py + s * ny * eps; sr.oz = pz + s * nz * eps;
     sr.dx = dx; sr.dy = dy; sr.dz = dz;
     sr.dlen = dsqrt(dx*dx + dy*dy + dz*dz);
-    return dsqrt(dist2);
+    return (1e-12 < len2) ? len : 1e-6;             // sqrt(max(1e-12, |L - p|^2)), raytracer.cpp:215
 }
 
 // An unblocked light's term, attenuation * (diffuse + specular) (raytracer.cpp:242-259); (dx,dy,dz) is the unit
