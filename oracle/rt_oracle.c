@@ -903,7 +903,7 @@ static void box_ray_init(box_ray* br, const double o[3], const double d[3], floa
 /* Slab test against the box grown by pad on every side, each plane's distance as one fused multiply-add (the product's
  * arithmetic, so that both walks visit the same boxes); returns the entry distance clamped to >= 0, or +inf when the
  * ray misses or the box starts beyond `limit`. */
-static float box_entry(const rto_node32* nd, const box_ray* br, float limit) {
+static inline float box_entry(const rto_node32* nd, const box_ray* br, float limit) {
     float tn = 0.0f, tf = limit;
     for (int k = 0; k < 3; ++k) {
         const float a = fmaf(nd->lo[k], br->inv[k], br->np[k]);
@@ -950,6 +950,11 @@ static int walk_slot(walk_state* w, uint32_t slot) {
 
 /* Generic walk.  mode 0: closest hit (tie -> lowest id).  mode 1: shadow verdict for a light at
  * light_dist - returns 1 when blocked by the reference's rule. */
+#if defined(__x86_64__) && defined(__GNUC__)
+/* fmaf() as one instruction where the CPU has it (function multiversioning; the plain clone calls libm); nothing else in
+ * here is contracted (-ffp-contract=off) */
+__attribute__((target_clones("fma", "default")))
+#endif
 static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int mode, double light_dist, rto_hit* out) {
     const rto_bvh* B = c->bvh;
     box_ray br; box_ray_init(&br, o, d, B->radius);
