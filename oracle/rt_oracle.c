@@ -880,6 +880,8 @@ void rto_render(const rto_scene* sc, const rto_camera* cam, int x0, int y0, int 
 
 typedef struct {
     const rto_scene* sc; const rto_bvh* bvh; int64_t* counts;
+    /* shadow walks of the frame pipeline: the primitive the ray starts on and the unit normal there (have_self != 0) */
+    int have_self; int32_t self_pid; double self_n[3];
 } bvh_ctx;
 
 typedef struct { float inv[3], np[3], nm[3]; } box_ray;   /* reciprocal direction, -(origin +/- pad) * reciprocal */
@@ -927,11 +929,13 @@ static float f32_up(double x) {            /* smallest float >= max(x, 0); NaN -
 typedef struct {
     const bvh_ctx* c; const double* o; const double* d; int mode; double light_dist;
     rto_hit best; double limit; float limit_f; int found_mid; int64_t vp;
+    int32_t skip_pid;                  /* the ray's own primitive when its test is known to miss, else -1 */
 } walk_state;
 
 /* One primitive slot; returns 1 when the walk can stop (shadow mode: a hit at <= 1e-4). */
 static int walk_slot(walk_state* w, uint32_t slot) {
     const uint32_t pid = w->c->bvh->slot_prim[slot];
+    if ((int32_t)pid == w->skip_pid) return 0;
     rto_hit h; w->vp += 1;
     if (!rto_intersect(&w->c->sc->prims[pid], w->o, w->d, &h)) return 0;
     if (w->mode == 0) {
@@ -960,6 +964,21 @@ static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int 
     box_ray br; box_ray_init(&br, o, d, B->radius);
     walk_state w; w.c = c; w.o = o; w.d = d; w.mode = mode; w.light_dist = light_dist;
     hit_clear(&w.best); w.found_mid = 0; w.vp = 0;
+    /* The product's frame pipeline passes over the test of the primitive a shadow ray starts on when it is known to miss:
+     * the primitive is convex and lies behind the tangent plane at the hit, the ray starts 1e-4 in front of that plane
+     * and does not point back at it.  True for a flat primitive on either side, for a solid with a proper scale when
+     * the ray leaves along the outward normal.  (The verdict cannot differ; the count of primitive tests does.) */
+    w.skip_pid = -1;
+    if (mode == 1 && c->have_self && c->self_pid >= 0 && !c->sc->instanced) {
+        const rto_prim* P = &c->sc->prims[c->self_pid];
+        const int outward = c->self_n[0]*d[0] + c->self_n[1]*d[1] + c->self_n[2]*d[2] >= 0.0;
+        if (P->kind == RTO_PLANE || P->kind == RTO_TRIANGLE) w.skip_pid = c->self_pid;
+        else {
+            const double* S = P->kind == RTO_SPHERE ? P->q + 3 : P->q + 6;
+            const int proper = S[0] > 0.0 && S[1] > 0.0 && S[2] > 0.0 && S[0] < 1e300 && S[1] < 1e300 && S[2] < 1e300;
+            if (proper && outward) w.skip_pid = c->self_pid;
+        }
+    }
     w.limit = (mode == 0) ? RTO_INF : (light_dist - 1e-4);   /* only hits with dist < limit matter */
     w.limit_f = f32_up(w.limit);
     /* The stack keeps, for every postponed child, its (first, count) and its box entry distance: a pop needs
@@ -1047,14 +1066,14 @@ static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int 
 int rto_bvh_closest_hit(const rto_scene* sc, const rto_bvh* bvh, const double o[3], const double d[3],
                         rto_hit* out, int64_t counts[2]) {
     int64_t local[2] = { 0, 0 };
-    bvh_ctx c = { sc, bvh, counts ? counts : local };
+    bvh_ctx c = { sc, bvh, counts ? counts : local, 0, -1, { 0.0, 0.0, 0.0 } };
     return bvh_walk(&c, o, d, 0, 0.0, out);
 }
 
 int rto_bvh_occluded(const rto_scene* sc, const rto_bvh* bvh, const double o[3], const double d[3],
                      double light_dist, int64_t counts[2]) {
     int64_t local[2] = { 0, 0 };
-    bvh_ctx c = { sc, bvh, counts ? counts : local };
+    bvh_ctx c = { sc, bvh, counts ? counts : local, 0, -1, { 0.0, 0.0, 0.0 } };
     return bvh_walk(&c, o, d, 1, light_dist, 0);
 }
 
@@ -1069,7 +1088,7 @@ void rto_bvh_trace_rays(const rto_scene* sc, const rto_bvh* bvh, const double* r
     #pragma omp parallel for schedule(dynamic, 64) num_threads(nt) reduction(+:c0, c1)
     for (int64_t i = 0; i < n; ++i) {
         int64_t pc[2] = { 0, 0 };
-        bvh_ctx c = { sc, bvh, pc };
+        bvh_ctx c = { sc, bvh, pc, 0, -1, { 0.0, 0.0, 0.0 } };
         bvh_walk(&c, rays6 + i*6, rays6 + i*6 + 3, 0, 0.0, &out[i]);
         c0 += pc[0]; c1 += pc[1];
     }
@@ -1088,10 +1107,11 @@ void rto_bvh_render(const rto_scene* sc, const rto_bvh* bvh, const rto_camera* c
             double o[3], d[3];
             rto_pixel_to_ray(cam, (double)(x0 + xx) + 0.5, (double)(y0 + yy) + 0.5, o, d);
             int64_t pc[2] = { 0, 0 }, sc_[2] = { 0, 0 };
-            bvh_ctx pctx = { sc, bvh, pc };
-            bvh_ctx sctx = { sc, bvh, sc_ };
+            bvh_ctx pctx = { sc, bvh, pc, 0, -1, { 0.0, 0.0, 0.0 } };
+            bvh_ctx sctx = { sc, bvh, sc_, 0, -1, { 0.0, 0.0, 0.0 } };
             rto_hit hit;
             bvh_walk(&pctx, o, d, 0, 0.0, &hit);
+            if (hit.hit) { sctx.have_self = 1; sctx.self_pid = hit.prim; normalize3(hit.n[0], hit.n[1], hit.n[2], sctx.self_n); }
             uint8_t c[3] = { 0, 0, 0 };
             if (sc->n_lights > 0) shade_with(sc, &hit, o, c, bvh_occluded_cb, &sctx, 0);
             const int64_t k = (int64_t)(yy / step) * ((w + step - 1) / step) + (xx / step);

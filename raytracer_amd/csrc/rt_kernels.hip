@@ -459,6 +459,7 @@ struct Walker {
     BoxRay br;
     Stack st;
     uint32_t cur;
+    uint32_t self_slot, self_ref;       // MODE 1: the record the ray starts on when its test is known to miss (or all ones)
     double limit; float limit_f;
     Best best;                          // MODE 0
     double light_dist;                  // MODE 1
@@ -466,6 +467,7 @@ struct Walker {
     uint32_t vn, vp;
 
     DEV void test_slot(const DevScene& sc, uint32_t slot) {
+        if (MODE == 1 && !INST && slot == self_slot) return;
         // kind and all 18 doubles in one go: waiting for the kind before asking for the numbers would put two trips
         // to memory one behind the other, and a record is rarely in a cache
         const rt_prim_rec* rec = sc.recs + slot;
@@ -498,6 +500,7 @@ struct Walker {
         st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
+        self_slot = REF_NONE; self_ref = 0xF0000000u;       // a leaf of fifteen: no tree has one, so cur never equals it
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
@@ -514,6 +517,10 @@ struct Walker {
             if (box_entry(lo, hi, br, limit_f) != __builtin_inff()) cur = make_ref(__float_as_uint(lo.w), __float_as_uint(hi.w));
         }
     }
+    // A shadow ray leaves the primitive it starts on: when that primitive's own test is known to miss (set_self), its
+    // leaf is passed over as soon as the walk arrives there, instead of waiting for a leaf round to find nothing.
+    DEV void set_self(uint32_t slot) { self_slot = slot; self_ref = (1u << 28) | slot; if (cur == self_ref) cur = st.pop(limit_f); }
+    DEV void skip_self() { if (MODE == 1 && !INST && cur == self_ref) cur = st.pop(limit_f); }
     DEV bool at_internal() const { return ref_internal(cur); }
     DEV bool done() const { return cur == REF_NONE; }
 
@@ -650,7 +657,7 @@ struct ShadeCounters { uint32_t shadow_rays, vn, vp; };
 
 // Shadow ray of RayTracer::shade (raytracer.cpp:210-228) from a surface point with unit normal n towards light L:
 // origin nudged 1e-4 along the normal on the light's side, unit direction.  Returns the light distance.
-DEV double shadow_ray(const rt_light& L, double px, double py, double pz, double nx, double ny, double nz, RayD& sr) {
+DEV double shadow_ray(const rt_light& L, double px, double py, double pz, double nx, double ny, double nz, RayD& sr, bool* outward = nullptr) {
     const double lx = L.pos[0] - px, ly = L.pos[1] - py, lz = L.pos[2] - pz;
     const double len2 = lx*lx + ly*ly + lz*lz;
     const double len = dsqrt(len2);                 // one root serves the direction and the light's distance
@@ -659,6 +666,7 @@ DEV double shadow_ray(const rt_light& L, double px, double py, double pz, double
     const double eps = 1e-4;
     const double ndl = nx*dx + ny*dy + nz*dz;
     const double s = (ndl >= 0.0) ? 1.0 : -1.0;
+    if (outward) *outward = ndl >= 0.0;             // the ray starts on the normal's side of the surface and leaves it
     sr.ox = px + s * nx * eps; sr.oy = py + s * ny * eps; sr.oz = pz + s * nz * eps;
     sr.dx = dx; sr.dy = dy; sr.dz = dz;
     sr.dlen = dsqrt(dx*dx + dy*dy + dz*dz);
@@ -957,15 +965,19 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         // trips to memory one behind the other in every swap.
                         const uint32_t o = p.valid ? p.out : 0u;
                         int32_t hid = fb.id[o];
+                        const uint32_t own = (!INST && fb.slot) ? fb.slot[o] : REF_NONE;      // with k_surface's marks
                         const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
                         const float4* entry = (WIDE && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
                         const rt_light L = sc.lights[light0 + g % n_batch];
                         asm volatile("" : "+v"(hid));                           // the loads stay up here
                         RayD r;
-                        const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r);
+                        bool outward;
+                        const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r, &outward);
                         if (p.valid && hid >= 0) {
                             out = o;
                             w.start(sc, r, deep.e, ld, entry);
+                            // the ray leaves the convex primitive it starts on (k_surface marked it): that one test is a miss
+                            if (!INST && ((own >> 31) || ((own >> 30) & (outward ? 1u : 0u)))) w.set_self(own & 0x0FFFFFFFu);
                             ++n_cast;
                             state = w.done() ? DONE : TRAV;
                         }
@@ -1015,6 +1027,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 pt_inner_lanes += 1; if (lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(true))) - 1)) pt_inner_it += 1;
 #endif
                 w.step_internal(sc);
+                w.skip_self();
                 if (__popcll(__ballot(w.at_internal())) * RT_INNER_EXIT_REL < in_flight) break;
             }
 #ifdef RT_PHASE_TIMING
@@ -1025,6 +1038,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 pt_leaf_lanes += 1; if (lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(true))) - 1)) pt_leaf_it += 1;
 #endif
                 w.step_leaf(sc);
+                w.skip_self();
             }
 #else
             while (w.at_internal()) w.step_internal(sc);
@@ -1107,6 +1121,24 @@ __global__ void __launch_bounds__(256) k_surface(DevScene sc, DevCamera cam, Pix
             best_record<(FLAGS & 4) != 0, INST>(sc, b, r, h, mat_id);
             // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
             fb.id[out] = mat_id;
+            if (!INST) {
+                // Marks for the shadow pass.  A shadow ray starts 1e-4 off this surface, on the side its light is on.
+                // The primitive is convex and lies behind the tangent plane at the hit; a ray that starts in front of that
+                // plane and does not point back at it cannot meet the primitive again.  Bit 31: flat (parallelogram,
+                // triangle) - true for either side.  Bit 30: solid with a proper scale - true when the ray leaves along
+                // the outward normal; towards the other side it starts inside and must be tested.
+                const rt_prim_rec* rec = sc.recs + slot;
+                const uint32_t kind = rec->kind;
+                uint32_t mark = 0;
+                if (kind == RT_PLANE || kind == RT_TRIANGLE) mark = 1u << 31;
+                else if (kind == RT_CUBE || kind == RT_CYLINDER || kind == RT_SPHERE) {
+                    const int k0 = kind == RT_SPHERE ? 3 : 12;
+                    const double s0 = rec->d[k0], s1 = rec->d[k0 + 1], s2 = rec->d[k0 + 2];
+                    const bool proper = s0 > 0.0 && s1 > 0.0 && s2 > 0.0 && s0 < 1e300 && s1 < 1e300 && s2 < 1e300;
+                    mark = proper ? 1u << 30 : 0u;
+                }
+                fb.slot[out] = slot | mark;
+            }
             if (FLAGS & 4) fb.albedo[out] = albedo_at(sc, sc.mats[mat_id], h.u, h.v);
             double nx, ny, nz; normalize3(h.nx, h.ny, h.nz, nx, ny, nz);   // shade() re-normalises (raytracer.cpp:182)
             fb.px[out] = h.px; fb.py[out] = h.py; fb.pz[out] = h.pz;
