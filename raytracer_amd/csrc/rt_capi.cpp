@@ -61,7 +61,10 @@ struct rt_ctx {
     void* static_scratch = nullptr;        // this GPU's copy of the library's fixed workspace (rt_render_rect_static)
     size_t static_scratch_bytes = 0;
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
-    int refill_min = RT_REFILL_MIN;
+    int refill_env = 0;                    // RT_REFILL_MIN from the environment (experiments); 0: the defaults below
+    // free lanes a persistent wave lets pile up before it swaps rays: walks through instances pay more per swap
+    // (100M-triangle frame at 32 / 40 / 48: 22.2 / 21.7 / 21.4 ms; one-level scenes are best at 32)
+    int refill() const { return refill_env ? refill_env : (sc.inst ? RT_REFILL_MIN_INST : RT_REFILL_MIN); }
     bool entry_search = true;              // start a tile's walks below the root where its beam allows (rt_ctx_set_entry_search)
     bool brute_force = false;              // closest-hit entry points test every primitive against every ray (rt_ctx_set_brute_force)
     // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
@@ -384,7 +387,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
             if (const char* env = std::getenv("RT_WAVES_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 32) per_cu = v; }
             c->max_waves = static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu;
             if (const char* env = std::getenv("RT_ENTRY_SEARCH")) c->entry_search = std::atoi(env) != 0;
-            if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_min = v; }
+            if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_env = v; }
         }
     }
     // this GPU's address of the library's fixed workspace, looked up once per device with the device current
@@ -775,7 +778,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
         if (fb.entry_p && level == 0) ctx->mark_end();
         ctx->mark_begin(0);
         RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting,
-                                 level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill_min));
+                                 level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill()));
         ctx->mark_end();
         for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
             const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
@@ -785,7 +788,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
             if (fb.entry_s) ctx->mark_end();
             ctx->mark_begin(1);
             RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
-                                    ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
+                                    ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
             ctx->mark_end();
             ctx->mark_begin(2);
             RT_HIP(rt_launch_bounce_resolve(ctx->stream, &ctx->sc, &dc, &fb, &lv, l0, nb, l0 == 0, l0 + nb >= n_lights, max_scatters,
@@ -815,7 +818,7 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     if (fb.entry_p) ctx->mark_end();
     ctx->mark_begin(0);
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
-                             &fb, ctx->d_ctr, q, ctx->refill_min));
+                             &fb, ctx->d_ctr, q, ctx->refill()));
     ctx->mark_end();
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
@@ -825,7 +828,7 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
         if (fb.entry_s) ctx->mark_end();
         ctx->mark_begin(1);
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
-                                ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
+                                ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
         ctx->mark_end();
         ctx->mark_begin(2);
         RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &dc, &fb, l0, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
@@ -844,11 +847,11 @@ int run_shadow_mask(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     if (fb.entry_p) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, nullptr, nullptr,
-                             &fb, ctx->d_ctr, q, ctx->refill_min));
+                             &fb, ctx->d_ctr, q, ctx->refill()));
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, n_lights, ctx->counting, &fb, ctx->d_ctr));
     RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * n_lights), 0, n_lights,
-                            ctx->counting, &fb, ctx->d_ctr, q, ctx->refill_min));
+                            ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
     RT_HIP(rt_launch_verdict_mask(ctx->stream, &fb, n_lights, mask_dev));
     return RT_OK;
 }
@@ -891,7 +894,7 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, dist_dev, nullptr,
-                             ctx->d_ctr, q, ctx->refill_min));
+                             ctx->d_ctr, q, ctx->refill()));
     return RT_OK;
 }
 
@@ -991,7 +994,7 @@ int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatter
             unsigned int* q = nullptr;
             if (int rc = next_queue(ctx, qb, &q)) return rc;
             RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
-                                     ctx->d_ctr, q, ctx->refill_min));
+                                     ctx->d_ctr, q, ctx->refill()));
         }
         return RT_OK;
     }
@@ -1034,7 +1037,7 @@ int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8
             unsigned int* q = nullptr;
             if (int rc = next_queue(ctx, qb, &q)) return rc;
             RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
-                                     ctx->d_ctr, q, ctx->refill_min));
+                                     ctx->d_ctr, q, ctx->refill()));
         }
         return RT_OK;
     }

@@ -460,6 +460,7 @@ struct Walker {
     Stack st;
     uint32_t cur;
     uint32_t self_slot, self_ref;       // MODE 1: the record the ray starts on when its test is known to miss (or all ones)
+    uint32_t self_inst;                 // ... and, in a two-level scene, the instance it belongs to
     double limit; float limit_f;
     Best best;                          // MODE 0
     double light_dist;                  // MODE 1
@@ -467,7 +468,7 @@ struct Walker {
     uint32_t vn, vp;
 
     DEV void test_slot(const DevScene& sc, uint32_t slot) {
-        if (MODE == 1 && !INST && slot == self_slot) return;
+        if (MODE == 1 && slot == self_slot && (!INST || inst == self_inst)) return;
         // kind and all 18 doubles in one go: waiting for the kind before asking for the numbers would put two trips
         // to memory one behind the other, and a record is rarely in a cache
         const rt_prim_rec* rec = sc.recs + slot;
@@ -501,6 +502,7 @@ struct Walker {
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
         self_slot = REF_NONE; self_ref = 0xF0000000u;       // a leaf of fifteen: no tree has one, so cur never equals it
+        self_inst = REF_NONE;
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
@@ -519,8 +521,11 @@ struct Walker {
     }
     // A shadow ray leaves the primitive it starts on: when that primitive's own test is known to miss (set_self), its
     // leaf is passed over as soon as the walk arrives there, instead of waiting for a leaf round to find nothing.
-    DEV void set_self(uint32_t slot) { self_slot = slot; self_ref = (1u << 28) | slot; if (cur == self_ref) cur = st.pop(limit_f); }
-    DEV void skip_self() { if (MODE == 1 && !INST && cur == self_ref) cur = st.pop(limit_f); }
+    DEV void set_self(uint32_t slot, uint32_t instance) {
+        self_slot = slot; self_ref = (1u << 28) | slot; self_inst = instance;
+        skip_self();
+    }
+    DEV void skip_self() { if (MODE == 1 && cur == self_ref && (!INST || inst == self_inst)) cur = st.pop(limit_f); }
     DEV bool at_internal() const { return ref_internal(cur); }
     DEV bool done() const { return cur == REF_NONE; }
 
@@ -965,7 +970,8 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         // trips to memory one behind the other in every swap.
                         const uint32_t o = p.valid ? p.out : 0u;
                         int32_t hid = fb.id[o];
-                        const uint32_t own = (!INST && fb.slot) ? fb.slot[o] : REF_NONE;      // with k_surface's marks
+                        const uint32_t own = fb.slot[o];                                   // with k_surface's marks
+                        const uint32_t own_inst = INST ? fb.inst[o] : REF_NONE;
                         const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
                         const float4* entry = (WIDE && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
                         const rt_light L = sc.lights[light0 + g % n_batch];
@@ -977,7 +983,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                             out = o;
                             w.start(sc, r, deep.e, ld, entry);
                             // the ray leaves the convex primitive it starts on (k_surface marked it): that one test is a miss
-                            if (!INST && ((own >> 31) || ((own >> 30) & (outward ? 1u : 0u)))) w.set_self(own & 0x0FFFFFFFu);
+                            if ((own >> 31) || ((own >> 30) & (outward ? 1u : 0u))) w.set_self(own & 0x0FFFFFFFu, own_inst);
                             ++n_cast;
                             state = w.done() ? DONE : TRAV;
                         }
@@ -1121,7 +1127,7 @@ __global__ void __launch_bounds__(256) k_surface(DevScene sc, DevCamera cam, Pix
             best_record<(FLAGS & 4) != 0, INST>(sc, b, r, h, mat_id);
             // the slot keeps the primitive whose material applies: in a two-level scene the mesh primitive
             fb.id[out] = mat_id;
-            if (!INST) {
+            {
                 // Marks for the shadow pass.  A shadow ray starts 1e-4 off this surface, on the side its light is on.
                 // The primitive is convex and lies behind the tangent plane at the hit; a ray that starts in front of that
                 // plane and does not point back at it cannot meet the primitive again.  Bit 31: flat (parallelogram,
