@@ -775,3 +775,55 @@ def test_random_scenes_against_brute_force(ctx, oracle, seed):
             assert_rgb_close(ctx.render(cam, max_scatters=ms), want[ms], max_frac=2e-3)
         rid, rdist = ctx.trace_rays(rays)
         assert np.array_equal(rid, a["id"]) and np.array_equal(bits(rdist), bits(a["dist"])), on_device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 17, 101, 2024])
+def test_shadow_verdicts_where_a_ray_leaves_its_own_primitive(ctx, oracle, seed):
+    """The shadow pass does not test a ray against the primitive it starts on when that test is known to miss.  Verdict
+    bits must still equal the every-primitive loop's (which tests everything, the ray's own primitive included) where that
+    rule is under strain: scales from 1e-3 to 1e3 and of either sign, lights inside solids, lights in a primitive's own
+    plane and grazing its surface, the camera inside a solid, coincident primitives."""
+    import torch
+    rng = np.random.default_rng(seed)
+    prims, lights, camd = S.random_scene(60, seed, kinds=(S.CUBE, S.PLANE, S.CYLINDER, S.SPHERE, S.TRIANGLE), lights=6)
+    prims = prims.copy()
+    for i in range(len(prims)):
+        k = int(prims["kind"][i])
+        if k in (S.CUBE, S.CYLINDER, S.SPHERE):
+            sl = slice(6, 9) if k != S.SPHERE else slice(3, 6)
+            r = rng.uniform()
+            if r < 0.15:
+                prims["q"][i, sl] *= rng.choice([1e-3, 1e3]) if seed % 2 else 1.0           # tiny / huge
+            elif r < 0.3:
+                prims["q"][i, sl] *= rng.choice([-1.0, 1.0], size=3)                         # mirrored axes
+            elif r < 0.35:
+                prims["q"][i, sl.start] = 0.0                                               # flattened: kept beside the tree
+    solids = [i for i in range(len(prims)) if int(prims["kind"][i]) in (S.CUBE, S.CYLINDER, S.SPHERE)]
+    flats = [i for i in range(len(prims)) if int(prims["kind"][i]) in (S.PLANE, S.TRIANGLE)]
+    lights = lights.copy()
+    lights["pos"][0] = prims["q"][solids[0], 0:3]                                           # inside a solid
+    lights["pos"][1] = prims["q"][solids[1], 0:3] + 1e-3
+    q = prims["q"][flats[0]]
+    lights["pos"][2] = q[0:3] + 0.3 * (q[3:6] - q[0:3]) + 0.6 * (q[6:9] - q[0:3])           # in a flat primitive's plane
+    lights["pos"][3] = q[0:3] + 5.0 * (q[3:6] - q[0:3])                                     # in that plane, far outside
+    twin = S.new_prims(2); twin[0] = prims[solids[2]]; twin[1] = prims[flats[1]]            # coincident copies
+    inside_at = prims["q"][solids[3], 0:3] + 1e-2                                            # a camera inside a solid
+    prims = S.sort_reference_order(np.concatenate([prims, twin]))
+    for where in ("outside", "inside"):
+        cd = dict(camd, res=(128, 72))
+        if where == "inside":
+            cd = dict(cd, location=list(inside_at))
+        cam = capi.make_camera(**cd)
+        ctx.upload(capi.Scene.create(prims, lights))
+        W, H = cam.width, cam.height
+        mask = torch.empty(H * W, dtype=torch.uint8, device="cuda")
+        ctx.trace_shadows_dev(cam, (0, 0, W, H), mask.data_ptr()); ctx.synchronize()
+        got = mask.cpu().numpy().reshape(H, W)
+        ys, xs = np.mgrid[0:H, 0:W]
+        rays = oracle.pixel_rays(ocamera(cam), np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], axis=1))
+        hits, lit, rgb = oracle.brute_shade_rays(oracle.scene(prims, lights), rays)
+        want = (lit.astype(np.uint32) << np.arange(lit.shape[1], dtype=np.uint32)).sum(1).astype(np.uint8).reshape(H, W)
+        want[hits["id"].reshape(H, W) < 0] = 0
+        assert (hits["id"] >= 0).mean() > 0.05
+        assert np.array_equal(got, want), "%d of %d verdict bytes differ (%s)" % ((got != want).sum(), got.size, where)
