@@ -74,7 +74,7 @@ def cpu_baseline(scene, prims, lights, camd, budget_s, threads, trials=3):
     O = bind.Oracle()
     osc = O.scene(prims, lights)
     nodes, slots, n_slots, n_loose, radius = scene.bvh()
-    bvh = O.bvh(nodes, slots, n_slots, n_loose, radius, scene.wide_bvh())
+    bvh = O.bvh(nodes, slots, n_slots, n_loose, radius, scene.wide_bvh(), scene.loose_boxes())
     cam = bind.camera_from_dict(O, camd)
     W, H = camd["res"]
     threads = threads or min(os.cpu_count() or 1, 16)

@@ -167,6 +167,10 @@ int rt_scene_get_prims(const rt_scene* scene, const rt_prim_desc** prims, uint64
 int rt_scene_get_lights(const rt_scene* scene, const rt_light** lights, uint32_t* n);
 int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n_nodes,
                      const uint32_t** slot_prim, uint64_t* n_slots);
+/* Boxes of the primitives kept beside the tree (rt_scene_info.n_loose of them, in slot order): 8 floats each - min xyz,
+ * unused, max xyz, unused - rounded outward; infinite for an unbounded primitive.  The kernels spare a ray the FP64
+ * test of such a primitive when the ray misses the padded box (the test of a box in the tree, no more and no less). */
+int rt_scene_get_loose_boxes(const rt_scene* scene, const float** boxes8, uint64_t* n);
 /* The hierarchy as the kernels walk it for host-built scenes: the binary tree collapsed into wide nodes (one 128-byte
  * fetch and four box tests per step instead of two steps; the same boxes, the same leaves).  For a two-level scene one
  * array holds the tree over the instances first and then each mesh's tree, inner references counted from the start of

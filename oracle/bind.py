@@ -42,7 +42,8 @@ class Camera(C.Structure):
 
 class Bvh(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_int64), ("slot_prim", C.c_void_p), ("n_slots", C.c_int64),
-                ("n_loose", C.c_int64), ("radius", C.c_float), ("nodes4", C.c_void_p), ("n_nodes4", C.c_int64)]
+                ("n_loose", C.c_int64), ("radius", C.c_float), ("nodes4", C.c_void_p), ("n_nodes4", C.c_int64),
+                ("loose_boxes", C.c_void_p)]
 
 
 class _Texture(C.Structure):
@@ -251,13 +252,19 @@ class Oracle:
         return lut
 
     @staticmethod
-    def bvh(nodes, slot_prim, n_slots, n_loose, radius, nodes4=None):
+    def bvh(nodes, slot_prim, n_slots, n_loose, radius, nodes4=None, loose_boxes=None):
         """Descriptor of the product's flattened BVH (numpy views from raytracer_amd.capi.Scene.bvh()); with nodes4
-        (Scene.wide_bvh()) the walk goes through the wide nodes, as the product's does when it has them."""
+        (Scene.wide_bvh()) the walk goes through the wide nodes, as the product's does when it has them; with loose_boxes
+        (Scene.loose_boxes()) the primitives beside the tree are culled by their boxes, as the product does."""
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DT)
         slot_prim = np.ascontiguousarray(slot_prim, dtype=np.uint32)
-        b = Bvh(_ptr(nodes), len(nodes), _ptr(slot_prim), int(n_slots), int(n_loose), float(radius), None, 0)
+        b = Bvh(_ptr(nodes), len(nodes), _ptr(slot_prim), int(n_slots), int(n_loose), float(radius), None, 0, None)
         b._keep = (nodes, slot_prim)
+        if loose_boxes is not None and len(loose_boxes):
+            loose_boxes = np.ascontiguousarray(loose_boxes, dtype=np.float32).reshape(-1, 8)
+            assert len(loose_boxes) == int(n_loose)
+            b.loose_boxes = _ptr(loose_boxes)
+            b._keep += (loose_boxes,)
         if nodes4 is not None and len(nodes4):
             nodes4 = np.ascontiguousarray(nodes4, dtype=NODE4_DT)
             b.nodes4, b.n_nodes4 = _ptr(nodes4), len(nodes4)

@@ -1057,7 +1057,14 @@ static int bvh_walk(const bvh_ctx* c, const double o[3], const double d[3], int 
         }
     }
     /* unbounded primitives are tested against every ray */
-    for (uint32_t s = 0; s < B->n_loose && !closed; ++s) closed = walk_slot(&w, (uint32_t)B->n_slots + s);
+    for (uint32_t s = 0; s < B->n_loose && !closed; ++s) {
+        if (B->loose_boxes) {          /* the product's cull: the padded box of the primitive, tested like a box of the tree */
+            rto_node32 nd;
+            for (int a = 0; a < 3; ++a) { nd.lo[a] = B->loose_boxes[8*s + a]; nd.hi[a] = B->loose_boxes[8*s + 4 + a]; }
+            if (box_entry(&nd, &br, w.limit_f) == __builtin_inff()) continue;
+        }
+        closed = walk_slot(&w, (uint32_t)B->n_slots + s);
+    }
     c->counts[0] += vn; c->counts[1] += w.vp;
     if (mode == 0) { if (out) *out = w.best; return w.best.hit; }
     return w.found_mid && !closed;

@@ -152,6 +152,9 @@ typedef struct rto_bvh {
     /* when set, the walk goes through the wide nodes exactly as the product's does (root box from nodes[0], then four
      * boxes per step, entered children ordered by a five-exchange network, nearest first) */
     const rto_node4* nodes4; int64_t n_nodes4;
+    /* optional (rt_scene_get_loose_boxes): 8 floats per loose primitive - min xyz, -, max xyz, -.  When set, a ray that
+     * misses a loose primitive's padded box is spared that primitive's test, as in the product. */
+    const float* loose_boxes;
 } rto_bvh;
 
 /* Closest hit through the BVH with FP32 padded boxes and FP64 leaf tests; same result as rto_closest_hit by

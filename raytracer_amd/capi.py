@@ -89,6 +89,7 @@ SYMBOLS = [
     ("rt_scene_get_prims", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U64)]),
     ("rt_scene_get_lights", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U32)]),
     ("rt_scene_get_bvh", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U32), C.POINTER(_VP), C.POINTER(_U64)]),
+    ("rt_scene_get_loose_boxes", C.c_int, [_VP, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("rt_scene_get_wide_bvh", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_U32)]),
     ("rt_scene_camera", C.c_int, [_VP, C.c_char_p, _I32, C.POINTER(Camera), C.c_char_p]),
     ("rt_prim_aabb", C.c_int, [_VP, _DP]),
@@ -336,6 +337,14 @@ class Scene:
         if total:
             slots = np.frombuffer((C.c_char * (total * 4)).from_address(ps.value), dtype=np.uint32).copy()
         return nodes, slots, int(ns.value), int(info.n_loose), float(np.nextafter(np.float32(info.radius), np.float32(np.inf)))
+
+    def loose_boxes(self):
+        """(n_loose, 8) float32: boxes of the primitives kept beside the tree (min xyz, -, max xyz, -)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(lib().rt_scene_get_loose_boxes(self.h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 8), np.float32)
+        return np.frombuffer((C.c_char * (n.value * 32)).from_address(p.value), dtype=np.float32).reshape(-1, 8).copy()
 
     def n_wide(self):
         """Number of wide nodes (0: the kernels walk the binary tree)."""

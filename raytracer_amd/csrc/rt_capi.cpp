@@ -49,6 +49,7 @@ struct rt_ctx {
     rt_node32* d_nodes = nullptr; rt_prim_rec* d_recs = nullptr; rt_mat_rec* d_mats = nullptr;
     rt_light* d_lights = nullptr; rt_counters* d_ctr = nullptr;
     uint8_t* d_texels = nullptr; rt_tex_rec* d_tex_table = nullptr;
+    float* d_loose_boxes = nullptr;        // boxes of the primitives beside the tree (8 floats each)
     rt_node4* d_nodes4 = nullptr;          // wide nodes (host-built: collapsed on the host; device-built: written by the builder)
     uint32_t n_nodes4_dev = 0;
     bool dev_wide = false; uint32_t dev_root_ref = 0; float dev_root_lo[3] = {}, dev_root_hi[3] = {};   // device-built scenes
@@ -97,7 +98,8 @@ struct rt_ctx {
         if (d_slot_prim) (void)hipFree(d_slot_prim);
         if (d_inst) (void)hipFree(d_inst);
         if (d_nodes4) (void)hipFree(d_nodes4);
-        d_nodes4 = nullptr;
+        if (d_loose_boxes) (void)hipFree(d_loose_boxes);
+        d_nodes4 = nullptr; d_loose_boxes = nullptr;
         d_slot_prim = nullptr; d_inst = nullptr;
         d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr; d_texels = nullptr; d_tex_table = nullptr;
         have_scene = false;
@@ -318,6 +320,13 @@ int rt_scene_get_bvh(const rt_scene* scene, const rt_node32** nodes, uint32_t* n
     if (scene->device_build) return fail(RT_ERR_NOT_FOUND, "this scene's hierarchy is built on the device: see rt_ctx_download_bvh");
     *nodes = scene->nodes.data(); *n_nodes = static_cast<uint32_t>(scene->nodes.size());
     *slot_prim = scene->slot_prim.data(); *n_slots = scene->n_slots;
+    return RT_OK;
+}
+
+int rt_scene_get_loose_boxes(const rt_scene* scene, const float** boxes8, uint64_t* n) {
+    if (!scene || !boxes8 || !n) return fail(RT_ERR_INVALID, "null argument");
+    *boxes8 = scene->loose_boxes.empty() ? nullptr : scene->loose_boxes.data();
+    *n = scene->loose_boxes.size() / 8;
     return RT_OK;
 }
 
@@ -641,6 +650,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     if (rc == RT_OK) rc = upload(scene->tex_table, &ctx->d_tex_table);
     if (rc == RT_OK) rc = upload(scene->inst_recs, &ctx->d_inst);
     if (rc == RT_OK && !scene->device_build) rc = upload(scene->nodes4, &ctx->d_nodes4);
+    if (rc == RT_OK) rc = upload(scene->loose_boxes, &ctx->d_loose_boxes);
     if (rc != RT_OK) { ctx->free_scene(); return rc; }
     DevScene& d = ctx->sc;
     d.nodes = ctx->d_nodes; d.recs = ctx->d_recs; d.mats = ctx->d_mats; d.lights = ctx->d_lights; d.gamma = ctx->d_gamma;
@@ -654,6 +664,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
     d.n_textures = static_cast<uint32_t>(scene->tex_table.size());
     ctx->n_nodes4_dev = !ctx->d_nodes4 ? 0u : (scene->device_build ? 2u * static_cast<uint32_t>(scene->n_slots) : static_cast<uint32_t>(scene->nodes4.size()));
     d.nodes4 = reinterpret_cast<const float4*>(ctx->d_nodes4);
+    d.loose_boxes = reinterpret_cast<const float4*>(ctx->d_loose_boxes);
     d.root_ref = scene->wide_root_ref;
     for (int k = 0; k < 3; ++k) { d.root_lo[k] = 0.0f; d.root_hi[k] = 0.0f; }
     if (ctx->d_nodes4 && !scene->device_build) for (int k = 0; k < 3; ++k) { d.root_lo[k] = scene->nodes[0].lo[k]; d.root_hi[k] = scene->nodes[0].hi[k]; }

@@ -38,6 +38,7 @@ struct DevScene {
     const uint8_t*     texels;     // albedo textures, 8-bit RGB
     const rt_tex_rec*  tex_table;
     const float4*      nodes4;     // wide nodes (8 x 16 bytes each), or null: walk the binary nodes
+    const float4*      loose_boxes;// per loose primitive: lo xyz -, hi xyz - (infinite: unbounded); null when there are none
     float root_lo[3], root_hi[3];  // wide walk: the root's box ...
     uint32_t root_ref;             // ... and where the walk goes once inside it: a wide node, or the leaf the root is
     const rt_inst_rec* inst;       // two-level scenes: instances in the leaf order of the top-level tree

@@ -603,8 +603,13 @@ struct Walker {
     }
 
     // Unbounded primitives (a zero or non-finite scale) are tested against every ray, after the walk.
+    // A ray that misses a loose primitive's padded box (or meets it beyond the search limit) is spared the FP64 test, as
+    // with a leaf of the tree; the box ray is the world's again by then.
     DEV void finish(const DevScene& sc) {
-        for (uint32_t s = 0; s < sc.n_loose && !closed; ++s) test_slot(sc, sc.n_slots + s);
+        for (uint32_t s = 0; s < sc.n_loose && !closed; ++s) {
+            if (!INST && box_entry(sc.loose_boxes[2u * s], sc.loose_boxes[2u * s + 1u], br, limit_f) == __builtin_inff()) continue;
+            test_slot(sc, sc.n_slots + s);
+        }
     }
     DEV bool hit() const { return best.id >= 0; }                  // MODE 0
     DEV bool blocked() const { return found_mid && !closed; }      // MODE 1

@@ -153,7 +153,7 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
     if (s->nodes4.size() >= (1ull << 28) || wide_need + 1 + wide_mesh_need >= RT_STACK_DEPTH_INST - 1) s->nodes4.clear();
     if (!s->nodes4.empty()) for (rt_inst_rec& r : s->inst_recs) r.root_ref = r.pad[0];
     for (rt_inst_rec& r : s->inst_recs) r.pad[0] = 0;
-    s->n_slots = s->recs.size(); s->n_loose = 0;
+    s->n_slots = s->recs.size(); s->n_loose = 0; s->loose_boxes.clear();
     s->device_build = false; s->boxes_f32.clear();
 
     info.n_prims = n; info.n_slots = s->n_slots; info.n_loose = 0;
@@ -184,6 +184,7 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
     std::vector<rt_prim_rec> bounded_recs; bounded_recs.reserve(n);
     std::vector<rt_box64> boxes; boxes.reserve(n);
     std::vector<rt_prim_rec> loose;
+    std::vector<std::pair<uint32_t, rt_box64>> loose_bounds;       // (id, box) of the bounded ones among them
     rt_scene_info& info = s->info;
     std::memset(&info, 0, sizeof(info));
     for (int k = 0; k < 3; ++k) { info.bounds[k] = INFINITY; info.bounds[3 + k] = -INFINITY; }
@@ -227,7 +228,7 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
             std::vector<uint8_t> out(boxes.size(), 0);
             for (const auto& b : big) out[b.second] = 1;
             for (uint32_t i = 0; i < boxes.size(); ++i) {
-                if (out[i]) loose.push_back(bounded_recs[i]);
+                if (out[i]) { loose.push_back(bounded_recs[i]); loose_bounds.emplace_back(bounded_recs[i].id, boxes[i]); }
                 else { keep_recs.push_back(bounded_recs[i]); keep_boxes.push_back(boxes[i]); }
             }
             std::sort(loose.begin(), loose.end(), [](const rt_prim_rec& a, const rt_prim_rec& b) { return a.id < b.id; });
@@ -258,7 +259,21 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
         s->recs.push_back(bounded_recs[bvh.order[slot]]);
         s->slot_prim.push_back(bounded_recs[bvh.order[slot]].id);
     }
-    for (const rt_prim_rec& r : loose) { s->recs.push_back(r); s->slot_prim.push_back(r.id); }
+    // boxes of the primitives beside the tree (FP32, rounded outward; everything for an unbounded one): a ray that misses
+    // the padded box is spared the primitive's FP64 test
+    s->loose_boxes.clear();
+    for (const rt_prim_rec& r : loose) {
+        s->recs.push_back(r); s->slot_prim.push_back(r.id);
+        float b[8] = { -INFINITY, -INFINITY, -INFINITY, 0.0f, INFINITY, INFINITY, INFINITY, 0.0f };
+        for (const auto& lb : loose_bounds)
+            if (lb.first == r.id)
+                for (int k = 0; k < 3; ++k) {
+                    float lo = static_cast<float>(lb.second.lo[k]); if (static_cast<double>(lo) > lb.second.lo[k]) lo = std::nextafterf(lo, -INFINITY);
+                    float hi = static_cast<float>(lb.second.hi[k]); if (static_cast<double>(hi) < lb.second.hi[k]) hi = std::nextafterf(hi, INFINITY);
+                    b[k] = lo; b[4 + k] = hi;
+                }
+        s->loose_boxes.insert(s->loose_boxes.end(), b, b + 8);
+    }
 
     info.n_prims = n; info.n_slots = s->n_slots; info.n_loose = s->n_loose;
     info.n_nodes = s->device_build ? rt_device_build_node_count(static_cast<uint32_t>(s->n_slots)) : static_cast<uint32_t>(s->nodes.size());

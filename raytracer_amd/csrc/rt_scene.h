@@ -23,6 +23,7 @@ struct rt_scene {
     uint32_t wide_root_ref = 0;                      // where the wide walk starts: wide node 0, or the leaf the root is
     std::vector<uint32_t>     slot_prim;             // slot -> id (bounded, BVH order; loose ones appended)
     uint64_t n_slots = 0, n_loose = 0;
+    std::vector<float>        loose_boxes;           // 8 floats per loose primitive: lo xyz, -, hi xyz, - (infinite: unbounded)
     rt_scene_info info{};
     // albedo textures (Mesh::setAlbedoTexture, mesh.h:47): pool of texels, one table entry per texture, and the
     // texture of each primitive (-1 = none)

@@ -36,7 +36,7 @@ def ctx():
 
 def oracle_bvh(oracle, sc):
     nodes, slots, n_slots, n_loose, radius = sc.bvh()
-    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh())      # walked the way the kernels walk it
+    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh(), sc.loose_boxes())      # walked the way the kernels walk it
 
 
 def ocamera(cam):

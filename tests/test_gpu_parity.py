@@ -147,7 +147,7 @@ def test_triangles_against_reference_planes(ctx):
 
 def oracle_bvh(oracle, sc):
     nodes, slots, n_slots, n_loose, radius = sc.bvh()
-    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh())      # walked the way the kernels walk it
+    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh(), sc.loose_boxes())      # walked the way the kernels walk it
 
 
 def ocamera(cam):
@@ -686,7 +686,7 @@ def test_hierarchy_built_on_the_device(ctx, oracle, name, cam_id):
     wide = ctx.download_wide_bvh()
     if info.n_slots >= 2:
         assert len(wide) == 2 * info.n_slots                # the builder wrote wide nodes beside the binary ones
-    b = oracle.bvh(nodes, slots, info.n_slots, info.n_loose, radius, wide)
+    b = oracle.bvh(nodes, slots, info.n_slots, info.n_loose, radius, wide, sc.loose_boxes())
     _, _, counts, hits = oracle.bvh_render(oracle.scene(prims, lights), b, ocamera(cam))
     ctx.set_counting(True); ctx.set_entry_search(False); ctx.reset_counters()     # the CPU walk starts at the root
     ctx.render(cam, max_scatters=0)

@@ -235,7 +235,7 @@ def test_bvh_depth_is_bounded_on_adversarial_input(oracle):
 
 def oracle_bvh(oracle, sc):
     nodes, slots, n_slots, n_loose, radius = sc.bvh()
-    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh())      # walked the way the kernels walk it
+    return oracle.bvh(nodes, slots, n_slots, n_loose, radius, sc.wide_bvh(), sc.loose_boxes())      # walked the way the kernels walk it
 
 
 @pytest.mark.parametrize("name,cam_id", SHIPPED)
