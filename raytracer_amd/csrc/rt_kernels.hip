@@ -459,7 +459,7 @@ struct Walker {
     BoxRay br;
     Stack st;
     uint32_t cur;
-    uint32_t self_slot, self_ref;       // MODE 1: the record the ray starts on when its test is known to miss (or all ones)
+    uint32_t self_ref;                  // MODE 1: leaf reference (one primitive) of the record the ray starts on when its test is known to miss
     uint32_t self_inst;                 // ... and, in a two-level scene, the instance it belongs to
     double limit; float limit_f;
     Best best;                          // MODE 0
@@ -468,7 +468,7 @@ struct Walker {
     uint32_t vn, vp;
 
     DEV void test_slot(const DevScene& sc, uint32_t slot) {
-        if (MODE == 1 && slot == self_slot && (!INST || inst == self_inst)) return;
+        if (MODE == 1 && ((1u << 28) | slot) == self_ref && (!INST || inst == self_inst)) return;
         // kind and all 18 doubles in one go: waiting for the kind before asking for the numbers would put two trips
         // to memory one behind the other, and a record is rarely in a cache
         const rt_prim_rec* rec = sc.recs + slot;
@@ -501,7 +501,7 @@ struct Walker {
         st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
-        self_slot = REF_NONE; self_ref = 0xF0000000u;       // a leaf of fifteen: no tree has one, so cur never equals it
+        self_ref = 0xF0000000u;             // a leaf of fifteen: no tree has one, so neither cur nor a slot ever equals it
         self_inst = REF_NONE;
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
@@ -522,7 +522,7 @@ struct Walker {
     // A shadow ray leaves the primitive it starts on: when that primitive's own test is known to miss (set_self), its
     // leaf is passed over as soon as the walk arrives there, instead of waiting for a leaf round to find nothing.
     DEV void set_self(uint32_t slot, uint32_t instance) {
-        self_slot = slot; self_ref = (1u << 28) | slot; self_inst = instance;
+        self_ref = (1u << 28) | slot; self_inst = instance;
         skip_self();
     }
     DEV void skip_self() { if (MODE == 1 && cur == self_ref && (!INST || inst == self_inst)) cur = st.pop(limit_f); }
