@@ -1,5 +1,5 @@
 #!/bin/bash
-# Measurement recipe of round 2, run on the GPU box from the repository root:
+# Measurement recipe behind profiles/r2, run on the GPU box from the repository root:
 #   bash profiles/collect_r2.sh
 # kernel stats of the bench command (rocprofv3 --kernel-trace --stats), then one PMC pass per counter group - HBM-side
 # reads, writes, L2 hits / misses, issue mix and lane utilisation, waits, the L1 request path - each in a run of its own,
