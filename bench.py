@@ -47,6 +47,15 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+def kernel_source_sha16():
+    """Names the kernels a measurement belongs to: a hash over the device sources and the headers they include."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("raytracer_amd/csrc/rt_kernels.hip", "raytracer_amd/csrc/rt_device.h", "raytracer_amd/csrc/rt_internal.h", "include/rt_hip.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def mean_sd(xs):
     xs = [float(x) for x in xs]
     m = sum(xs) / len(xs)
@@ -201,6 +210,13 @@ def main():
         ctx.upload(scene)          # the first build also loads the builder's code objects: report a build in steady state
 
     tiling = capi.Tiling(W, H, args.tile, world)
+    # N > 1: an event between a rank's render and the exchange, so that the line shows compute and gather apart
+    splits = []
+    def split_mark():
+        if splits is not None and len(splits) < 4096:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            splits.append(e)
     gather_path = "rt_gather_tiles (RCCL send / grouped recv)"
     if world == 1:
         frame = torch.empty(H * W * 3, dtype=torch.uint8, device="cuda")
@@ -213,6 +229,7 @@ def main():
             tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
             def step():
                 ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
+                split_mark()
                 gathered = tg.gather()
                 if rank == 0:
                     ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
@@ -239,6 +256,7 @@ def main():
                 tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
                 def step():
                     ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
+                    split_mark()
                     gathered = tg.gather()
                     if rank == 0:
                         ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
@@ -246,6 +264,7 @@ def main():
                 local = torch.zeros(capi.tiles_per_rank(tiling) * args.tile * args.tile * 3, dtype=torch.uint8, device="cuda")
                 def step():
                     ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
+                    split_mark()
                     comm.gather_tiles(tiling, local.data_ptr(), frame.data_ptr() if rank == 0 else None)
 
     def fence():
@@ -283,6 +302,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    del splits[:]
     ctx.set_timing(True)          # HIP events around every launch, on the stream the kernels run on
     ctx.timing()
     # one more pair of events per step, on the same stream, for the spread over the steps
@@ -295,6 +315,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    # per step on this rank: render = step start -> split, exchange (gather + assembly, and on rank 0 the wait for the
+    # slowest peer) = split -> step end
+    render_ms = [marks[k].elapsed_time(splits[k]) for k in range(args.steps)] if len(splits) == args.steps else None
+    gather_ms = [splits[k].elapsed_time(marks[k + 1]) for k in range(args.steps)] if len(splits) == args.steps else None
     tm = ctx.timing()
     ctx.set_timing(False)
     # the shadow pass dominates (about 70 % of the frame): one launch per batch of up to 8 lights and per bounce level
@@ -309,6 +333,14 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, k_ms_max = (float(v) for v in t.tolist())
+    # what every rank did: rays of its share, mean render and exchange time per step
+    mine = torch.tensor([c["primary_rays"] + c["shadow_rays"] + c["bounce_rays"],
+                         sum(render_ms) / len(render_ms) if render_ms else elapsed / args.steps * 1e3,
+                         sum(gather_ms) / len(gather_ms) if gather_ms else 0.0], dtype=torch.float64, device="cuda")
+    per_rank = [mine.clone() for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(v) for v in r.tolist()] for r in per_rank]
 
     if rank == 0:
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
@@ -319,9 +351,10 @@ def main():
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         for name in sorted((f for f in os.listdir(pdir) if f.endswith("_traffic.json")), reverse=True):
             tj = json.load(open(os.path.join(pdir, name)))
+            # a measurement belongs to one set of kernels on one workload: the file must carry this build's source hash
             if (world == 1 and args.max_scatters == 0 and tj["workload"]["n_side"] == args.n_side
                     and tj["workload"]["rays_per_frame"] == rays_per_frame and tj.get("res", "3840x2160") == "%dx%d" % (W, H)
-                    and tj.get("algorithmic_bytes_per_launch") == k_bytes):
+                    and tj.get("algorithmic_bytes_per_launch") == k_bytes and tj.get("kernel_source_sha16") == kernel_source_sha16()):
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + name
                 break
         # the ceiling of the walk's node fetches: wide nodes per second with every lane on its own L1-resident node
@@ -355,6 +388,8 @@ def main():
                 "hierarchy": "Morton order cut top-down at the highest differing key bit, built on the GPU in %.2f ms" % ctx.build_time_ms() if args.device_build
                              else ("binned SAH on the host: one tree over the instances, one per mesh" if args.instanced else "binned SAH, built on the host"),
                 "arithmetic": "FP32 padded-box traversal through 4-wide nodes, FP64 leaf tests and shading",
+                "kernel_source_sha16": kernel_source_sha16(),
+                "rays_per_frame_by_rank": [int(r[0]) for r in per_rank],
             },
             "ms_per_step_device": {"mean": ms_mean, "sd": ms_sd, "min": min(step_ms), "max": max(step_ms), "n": len(step_ms),
                                    "what": "HIP events around each step on the kernels' stream (rank 0)"},
@@ -384,6 +419,11 @@ def main():
                 "kernel": kname, "kernel_ms": k_ms, "kernel_ms_max_over_ranks": k_ms_max,
                 "algorithmic_bytes_per_launch": k_bytes,
                 "stage_ms_per_frame": stage_ms,
+                # N > 1, per rank: its render (all stages of its share) and the exchange that follows (gather + assembly;
+                # on rank 0 this includes waiting for the slowest peer), HIP events on each rank's stream, mean per step
+                "render_ms_by_rank": [r[1] for r in per_rank] if world > 1 else None,
+                "gather_ms_by_rank": [r[2] for r in per_rank] if world > 1 else None,
+                "gather_ms": per_rank[0][2] if world > 1 else None,
                 "frame_algorithmic_bytes": frame_bytes,
                 "frame_achieved_GBps": frame_bytes / (device_ms * 1e-3) / 1e9 if device_ms > 0 else None,
                 "nodes_per_primary_ray": c["nodes_primary"] / max(c["primary_rays"], 1),

@@ -245,15 +245,22 @@ int rt_render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scat
 int rt_trace_shadows(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* lit_mask_dev);
 /* rt_render_rect with max_scatters = 0 for callers that cannot allocate device memory: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The frame working
- * set (80 bytes per pixel: hit points, normals, light sums, record slots, shadow verdicts) and the work-queue heads
- * live in a fixed workspace compiled into the library - a __device__ array of 84 bytes per pixel of the limit below
- * (21 MiB), of which every GPU the library runs on holds its own copy until the process ends - so the call makes no
- * hipMalloc / hipFree and calls no allocating routine.  Limit: rect.w * rect.h <= RT_STATIC_MAX_PIXELS (262144, e.g.
- * 512 x 512); larger rectangles return RT_ERR_LIMIT - render them in pieces.  Launch timing (rt_ctx_set_timing)
- * must be off (RT_ERR_INVALID otherwise: it creates events).  All calls on one GPU share that GPU's workspace: calls
- * that overlap in time on one GPU (two contexts, two streams) race; calls ordered on one stream do not, and each call
- * clears what it needs cleared.  Outputs are byte-identical to rt_render_rect's. */
+ * set (72 bytes per pixel: hit points, normals, light sums, record slots; 64 bytes of shadow verdicts per 8 x 8 tile and
+ * light of a batch), the work-queue heads and up to 5 MiB of per-tile planes of the entry search live in a fixed
+ * workspace compiled into the library - one __device__ array of 18 MiB + 4 MiB + 5 MiB (27.0 MiB, RT_STATIC_SCRATCH_BYTES
+ * in rt_device.h), of which every GPU the library runs on holds its own copy until the process ends - so the call makes
+ * no hipMalloc / hipFree and calls no allocating routine.  Limits: rect.w * rect.h <= RT_STATIC_MAX_PIXELS (262144, e.g.
+ * 512 x 512), and the rectangle, cut into blocks of 128 x 128 pixels from its top left corner, spans at most
+ * RT_STATIC_MAX_TILES / 256 = 32 blocks (only a strip thinner than 32 pixels can have the pixels and not the blocks);
+ * beyond either the call returns RT_ERR_LIMIT - render in pieces.  A call whose tiles and lights need more than the
+ * 5 MiB of per-tile planes (more than 4096 tiles with 8 lights, say) runs without the entry search: same bytes out,
+ * more boxes tested.  Launch timing (rt_ctx_set_timing) must be off (RT_ERR_INVALID otherwise: it creates events).  All
+ * calls on one GPU share that GPU's workspace: calls that overlap in time on one GPU (two contexts, two streams) race;
+ * calls ordered on one stream do not, and each call clears what it needs cleared.  The stream must be set before a
+ * capture begins (rt_ctx_set_stream orders the new stream behind the old one with an event, which a capturing stream
+ * cannot wait for; a capturing stream is taken as it is).  Outputs are byte-identical to rt_render_rect's. */
 #define RT_STATIC_MAX_PIXELS 262144u
+#define RT_STATIC_MAX_TILES 8192u
 int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8_t* rgb_dev, int32_t* hit_id_dev);
 /* The same loop with samples_per_pixel > 1 (raytracer.cpp:403-436): sample 0 through the pixel centre, later samples
  * offset by up to half a pixel; per-sample linear 8-bit colours are averaged, rounded, then gamma encoded.  The

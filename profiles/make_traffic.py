@@ -30,6 +30,8 @@ def main(src, dst):
     out = {
         "kernel": KERNEL,
         "workload": {k: bench["config"][k] for k in ("n_side", "n_prims", "rays_per_frame", "max_scatters")},
+        "kernel_source_sha16": bench["config"].get("kernel_source_sha16"),
+        "res": bench["metric"].rsplit(" ", 1)[-1],
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
         "metric": bench["metric"],
         "fetch_size_kib_per_launch": fetch[KERNEL], "write_size_kib_per_launch": write[KERNEL],

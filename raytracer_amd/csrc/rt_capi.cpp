@@ -59,6 +59,7 @@ struct rt_ctx {
     double build_ms = 0.0;
     uint8_t* d_gamma = nullptr;            // 256 bytes of the display transfer table, then 256 bytes of identity
     unsigned int* d_queue = nullptr;       // kQueueSlots work-queue heads, one per launch of a pipeline call
+    hipEvent_t switch_event = nullptr;     // orders a stream switch; created with the context so that a switch allocates nothing
     void* static_scratch = nullptr;        // this GPU's copy of the library's fixed workspace (rt_render_rect_static)
     size_t static_scratch_bytes = 0;
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
@@ -104,8 +105,11 @@ struct rt_ctx {
         d_nodes = nullptr; d_recs = nullptr; d_mats = nullptr; d_lights = nullptr; d_texels = nullptr; d_tex_table = nullptr;
         have_scene = false;
     }
+    // Grow-only buffer `slot` of at least `bytes`, on THIS context's GPU whatever device the caller left current (a
+    // process that drives several GPUs calls this for one context after working on another).
     int need(int slot, size_t bytes, void** out) {
         if (scratch_bytes[slot] < bytes) {
+            RT_HIP(hipSetDevice(device));
             if (scratch[slot]) (void)hipFree(scratch[slot]);
             scratch[slot] = nullptr; scratch_bytes[slot] = 0;
             RT_HIP(hipMalloc(&scratch[slot], bytes));
@@ -385,6 +389,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     c->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->switch_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_ctr), kCounterBytes);
     if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, kCounterBytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_queue), kQueueSlots * sizeof(unsigned int));
@@ -427,6 +432,7 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     for (void* p : ctx->scratch) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RT_OK;
@@ -434,16 +440,20 @@ int rt_ctx_destroy(rt_ctx* ctx) {
 
 namespace {
 // The frame working set, the queue heads and the counters are shared by whatever stream the context launches on: work
-// queued on the new stream must start after what is still pending on the old one.
+// queued on the new stream must start after what is still pending on the old one.  The event that orders the two is the
+// context's own (nothing is allocated here).  A stream that is being captured cannot wait on an event recorded outside
+// its capture; such a stream is taken as it is, and the caller orders it against the old stream's pending work (set the
+// stream before the capture begins, or synchronise first).
 int switch_stream(rt_ctx* ctx, hipStream_t to) {
     if (to == ctx->stream) return RT_OK;
     if (int rc = use(ctx)) return rc;
-    hipEvent_t done = nullptr;
-    RT_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(done, ctx->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(to, done, 0);
-    (void)hipEventDestroy(done);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("stream switch: ") + hipGetErrorString(e));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (to && hipStreamIsCapturing(to, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone) {
+        hipError_t e = hipEventRecord(ctx->switch_event, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(to, ctx->switch_event, 0);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("stream switch: ") + hipGetErrorString(e));
+    }
     ctx->stream = to;
     return RT_OK;
 }
@@ -577,7 +587,7 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
             uint8_t need0 = 255;
             if (rc == RT_OK && want_wide) check(hipMemcpy(&need0, d_need, 1, hipMemcpyDeviceToHost), "hipMemcpy");
             for (int k = 0; k < 3; ++k) { ctx->dev_root_lo[k] = root.lo[k]; ctx->dev_root_hi[k] = root.hi[k]; }
-            ctx->dev_wide = rc == RT_OK && want_wide && root.count == 0 && need0 < RT_STACK_DEPTH_INST - 1;
+            ctx->dev_wide = rc == RT_OK && want_wide && root.count == 0 && need0 < RT_WIDE_STACK_LIMIT;
         }
     }
     if (t0) (void)hipEventDestroy(t0);
@@ -710,13 +720,12 @@ uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
     return static_cast<uint32_t>(want < ctx->max_waves ? want : ctx->max_waves);
 }
 
-// The frame working set of n output slots laid over a block of memory: 7 planes of doubles, four of 32-bit words, one
-// verdict byte per slot and light of a batch.
+// The frame working set of n output slots laid over a block of memory: 7 planes of doubles, four of 32-bit words.
 constexpr size_t kFramePlanes = 7;
-size_t frame_bytes(size_t n, uint32_t n_batch) {
-    (void)n_batch;
-    return n * (kFramePlanes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t) + RT_LIGHT_BATCH) + 256;
-}
+static_assert(RT_FRAME_BYTES_PER_SLOT == kFramePlanes * sizeof(double) + sizeof(int32_t) + 3 * sizeof(uint32_t), "frame planes");
+size_t frame_bytes(size_t n) { return n * RT_FRAME_BYTES_PER_SLOT + 256; }
+// Shadow verdicts of one batch of lights, in ray order: 64 bytes per 8x8 tile of the pixel map and light.
+size_t verdict_bytes(size_t n_tiles, uint32_t n_batch) { return n_tiles * 64u * n_batch + 256; }
 // Per-tile planes of the entry search: the box of the tile's hits, one entry node for its camera rays and one per light of
 // a batch for its shadow rays.
 size_t tile_bytes(size_t n_tiles, uint32_t n_batch) { return n_tiles * RT_TILE_BYTES(n_batch) + 256; }
@@ -735,18 +744,20 @@ void carve_frame(void* base, size_t n, bool textures, FrameBufs& fb) {
     fb.ray = nullptr; fb.rawn = nullptr; fb.alive = nullptr; fb.level = 0;
     fb.albedo = textures ? reinterpret_cast<uint32_t*>(fb.id + n) : nullptr;
     fb.slot = reinterpret_cast<uint32_t*>(fb.id + 2 * n); fb.inst = fb.slot + n;
-    fb.lit = reinterpret_cast<uint8_t*>(fb.id + 4 * n);
+    fb.lit = nullptr;
 }
 
 // The same out of the context's grow-only scratch (allocated on first use of a size).
 bool wants_entry_search(const rt_ctx* ctx) { return ctx->entry_search && ctx->sc.nodes4; }
 int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, size_t n_tiles, FrameBufs& fb) {
     void* base = nullptr;
-    const size_t fbytes = (frame_bytes(n, n_batch) + 255u) & ~static_cast<size_t>(255);
+    const size_t fbytes = (frame_bytes(n) + 255u) & ~static_cast<size_t>(255);
+    const size_t vbytes = (verdict_bytes(n_tiles, n_batch) + 255u) & ~static_cast<size_t>(255);
     const bool entry = wants_entry_search(ctx);
-    if (int rc = ctx->need(3, fbytes + (entry ? tile_bytes(n_tiles, n_batch) : 0), &base)) return rc;
+    if (int rc = ctx->need(3, fbytes + vbytes + (entry ? tile_bytes(n_tiles, n_batch) : 0), &base)) return rc;
     carve_frame(base, n, ctx->sc.n_textures != 0, fb);
-    if (entry) carve_tiles(static_cast<uint8_t*>(base) + fbytes, n_tiles, fb);
+    fb.lit = static_cast<uint8_t*>(base) + fbytes;
+    if (entry) carve_tiles(static_cast<uint8_t*>(base) + fbytes + vbytes, n_tiles, fb);
     return RT_OK;
 }
 
@@ -802,7 +813,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
                                     ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
             ctx->mark_end();
             ctx->mark_begin(2);
-            RT_HIP(rt_launch_bounce_resolve(ctx->stream, &ctx->sc, &dc, &fb, &lv, l0, nb, l0 == 0, l0 + nb >= n_lights, max_scatters,
+            RT_HIP(rt_launch_bounce_resolve(ctx->stream, &ctx->sc, &dc, &pm, &fb, &lv, l0, nb, l0 == 0, l0 + nb >= n_lights, max_scatters,
                                             min_scatter_intensity));
             ctx->mark_end();
         }
@@ -842,7 +853,7 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
         ctx->mark_end();
         ctx->mark_begin(2);
-        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &dc, &fb, l0, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
+        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &dc, &pm, &fb, l0, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
         ctx->mark_end();
     }
     return RT_OK;
@@ -863,7 +874,7 @@ int run_shadow_mask(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, n_lights, ctx->counting, &fb, ctx->d_ctr));
     RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * n_lights), 0, n_lights,
                             ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
-    RT_HIP(rt_launch_verdict_mask(ctx->stream, &fb, n_lights, mask_dev));
+    RT_HIP(rt_launch_verdict_mask(ctx->stream, &pm, &fb, n_lights, mask_dev));
     return RT_OK;
 }
 
@@ -1036,9 +1047,17 @@ int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8
     const uint32_t n_lights = ctx->sc.n_lights;
     const uint32_t batch = n_lights < RT_LIGHT_BATCH ? n_lights : RT_LIGHT_BATCH;
     const size_t queue_bytes = (kQueueSlots * sizeof(unsigned int) + 255u) & ~static_cast<size_t>(255);
-    if (n_out > RT_STATIC_MAX_PIXELS || queue_bytes + frame_bytes(n_out, batch) > ctx->static_scratch_bytes)
+    const size_t fbytes = (frame_bytes(n_out) + 255u) & ~static_cast<size_t>(255);
+    const size_t vbytes = (verdict_bytes(nw, batch) + 255u) & ~static_cast<size_t>(255);
+    if (n_out > RT_STATIC_MAX_PIXELS)
         return fail(RT_ERR_LIMIT, "rt_render_rect_static: rectangle of " + std::to_string(n_out) + " pixels exceeds the fixed workspace (at most "
                                   + std::to_string(RT_STATIC_MAX_PIXELS) + " pixels per call); render it in pieces or use rt_render_rect");
+    // the pixel map covers the rectangle with blocks of 128 x 128 pixels (256 tiles each); the verdict plane has room for
+    // RT_STATIC_MAX_TILES tiles, i.e. 32 such blocks - every rectangle of the pixel limit that is not a thin strip
+    if (nw > RT_STATIC_MAX_TILES || queue_bytes + fbytes + vbytes > ctx->static_scratch_bytes)
+        return fail(RT_ERR_LIMIT, "rt_render_rect_static: a rectangle of " + std::to_string(rect.w) + " x " + std::to_string(rect.h)
+                                  + " pixels spans " + std::to_string(nw / 256u) + " blocks of 128 x 128 pixels; the fixed workspace takes "
+                                  + std::to_string(RT_STATIC_MAX_TILES / 256u) + " (render a thin strip in shorter pieces, or use rt_render_rect)");
     if (ctx->timing) return fail(RT_ERR_INVALID, "rt_render_rect_static: launch timing creates events; switch it off (rt_ctx_set_timing)");
     DevCamera dc; to_dev_camera(*cam, dc);
     if (n_lights == 0) {        // the reference's all-black frame (raytracer.cpp:387-395); ids on request
@@ -1052,13 +1071,13 @@ int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8
         }
         return RT_OK;
     }
-    // queue heads first (zeroed by the pipeline's first launch), then the frame working set; every plane a launch reads
+    // queue heads first (zeroed by the pipeline's first launch), then the frame planes, the verdicts, the tile planes; every plane a launch reads
     // is written earlier in the same call, so what the previous call left in the workspace is never seen
     FrameBufs fb;
     carve_frame(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes, n_out, ctx->sc.n_textures != 0, fb);
-    const size_t fbytes = (frame_bytes(n_out, batch) + 255u) & ~static_cast<size_t>(255);
-    if (wants_entry_search(ctx) && queue_bytes + fbytes + tile_bytes(nw, batch) <= ctx->static_scratch_bytes)
-        carve_tiles(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes + fbytes, nw, fb);
+    fb.lit = static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes + fbytes;
+    if (wants_entry_search(ctx) && queue_bytes + fbytes + vbytes + tile_bytes(nw, batch) <= ctx->static_scratch_bytes)
+        carve_tiles(static_cast<uint8_t*>(ctx->static_scratch) + queue_bytes + fbytes + vbytes, nw, fb);
     return run_pipeline_on(ctx, dc, pm, nw, n_out, rgb_dev, hit_id_dev, fb, static_cast<unsigned int*>(ctx->static_scratch));
 }
 

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -51,11 +52,16 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // RT_RCCL_LIBRARY names the one file to load instead (a differently named build; tests use it to force a miss)
+        const char* forced = std::getenv("RT_RCCL_LIBRARY");
+        std::string last;                                // dlerror() hands a message out once and then forgets it: keep a copy
         for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            r.handle = dlopen(forced ? forced : name, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
+            if (const char* m = dlerror()) last = m;
+            if (forced) break;
         }
-        if (!r.handle) { r.error = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+        if (!r.handle) { r.error = std::string("RCCL not found: ") + (last.empty() ? std::string("dlopen failed") : last); return; }
         auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("RCCL lacks ") + n; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));

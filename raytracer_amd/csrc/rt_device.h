@@ -24,10 +24,12 @@
 // its hits (24 bytes, padded to 32)
 #define RT_ENTRY_NODE_BYTES 128u
 #define RT_TILE_BYTES(n_batch) (RT_ENTRY_NODE_BYTES * (1u + (n_batch)) + 32u)
-// workspace of rt_render_rect_static: 80 bytes per pixel, the queue heads, and 4 MiB for per-tile planes (a call whose
-// tiles need more goes without the entry search; results are the same either way)
-#define RT_STATIC_TILE_BYTES (4u << 20)
-#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * 80u + 4096u + RT_STATIC_TILE_BYTES)
+// workspace of rt_render_rect_static: the frame planes (72 bytes per pixel), the queue heads, the shadow verdicts of one
+// batch of lights (64 bytes per 8x8 tile and light) and 5 MiB for the entry search's per-tile planes (a call whose tiles
+// need more goes without the entry search; results are the same either way)
+#define RT_FRAME_BYTES_PER_SLOT 72u
+#define RT_STATIC_TILE_BYTES (5u << 20)
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_MAX_PIXELS * RT_FRAME_BYTES_PER_SLOT + 4096u + RT_STATIC_MAX_TILES * 64u * RT_LIGHT_BATCH + 512u + RT_STATIC_TILE_BYTES)
 
 struct DevScene {
     const rt_node32*   nodes;      // root at 0, sibling pairs at even indices
@@ -71,7 +73,7 @@ struct FrameBufs {
     double *px, *py, *pz;          // hit point
     double *nx, *ny, *nz;          // unit normal, re-normalised as RayTracer::shade does
     double *lighting;              // running light sum between light batches
-    uint8_t *lit;                  // [n][RT_LIGHT_BATCH] 1 = the light of the batch reaches the point (shadow verdict)
+    uint8_t *lit;                  // [tiles][lights of the batch][64] shadow verdicts in ray order: 1 = the light reaches the point
     int32_t *id;                   // primitive whose material applies to the hit, -1 = miss / padding
     uint32_t *slot, *inst;         // what the closest-hit launch found: record slot (all ones = nothing), instance slot
     size_t n;
@@ -110,9 +112,9 @@ hipError_t rt_launch_entry_search(hipStream_t st, const DevScene* sc, const DevC
 hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm,
                             uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
-hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, uint32_t light0, uint32_t n_batch,
+hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const FrameBufs* fb, uint32_t light0, uint32_t n_batch,
                              int first, int last, uint8_t* rgb);
-hipError_t rt_launch_verdict_mask(hipStream_t st, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask);
+hipError_t rt_launch_verdict_mask(hipStream_t st, const PixelMap* pm, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr);
 // Every primitive against every ray (no hierarchy); rays = null: the camera rays of the rectangle in pm, row-major.
@@ -123,7 +125,7 @@ hipError_t rt_launch_finish_samples(hipStream_t st, const uint32_t* acc, size_t 
 hipError_t rt_launch_intersect_one(hipStream_t st, const rt_prim_rec* rec, const double* rays, uint64_t n, double* records);
 hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, const double* hits, const double* view, uint64_t n,
                                 uint8_t* rgb, rt_counters* ctr);
-hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, const LevelBufs* lv,
+hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const FrameBufs* fb, const LevelBufs* lv,
                                     uint32_t light0, uint32_t n_batch, int first, int last, int max_scatters, double min_si);
 hipError_t rt_launch_bounce_fold(hipStream_t st, const DevScene* sc, const LevelBufs* lv, size_t n, uint8_t* rgb);
 hipError_t rt_device_build_workspace(uint32_t n, size_t* bytes);

@@ -42,6 +42,12 @@ struct rt_inst_rec {
 };
 
 #define RT_STACK_DEPTH_INST 64     // two-level scenes: both trees and the marker between them
+// A walk that starts from a tile's entry node (up to four subtrees of the hierarchy picked for the tile) can have three
+// of them waiting on the stack before it descends into the fourth, where a walk from the root reaches that subtree with
+// fewer entries pushed: peak use is at most (what the collapsed tree needs) + RT_ENTRY_STACK_EXTRA.  Every gate that
+// decides whether a tree may be walked through its wide nodes keeps that margin.
+#define RT_ENTRY_STACK_EXTRA 3
+#define RT_WIDE_STACK_LIMIT (RT_STACK_DEPTH_INST - 1 - RT_ENTRY_STACK_EXTRA)   // largest `need` the wide walk accepts
 #define RT_STACK_DEPTH 32          // traversal stack entries per lane; the builder keeps depth <= 31
 #define RT_MAX_SCATTERS 8
 #define RT_PAD_SHIFT 18            // FP32 box padding = 2^-18 * max(|ray origin|, scene radius)

@@ -163,10 +163,14 @@ template <bool FULL> DEV bool solve_cylinder(const double ro[3], const double rd
 }
 
 // 16-byte loads of a record's doubles into registers.
+typedef double rt_d2 __attribute__((ext_vector_type(2)));
 template <int N> DEV void load_rec(const rt_prim_rec* rec, double (&c)[18]) {
-    const double2* v = reinterpret_cast<const double2*>(rec);
+    const rt_d2* v = reinterpret_cast<const rt_d2*>(rec);
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) { const double2 t = v[i]; c[2*i] = t.x; c[2*i + 1] = t.y; }
+    for (int i = 0; i < N / 2; ++i) {
+        const rt_d2 t = v[i];
+        c[2*i] = t.x; c[2*i + 1] = t.y;
+    }
     if (N & 1) c[N - 1] = rec->d[N - 1];
 }
 
@@ -850,6 +854,29 @@ DEV Pixel map_pixel(const PixelMap& pm, uint32_t w, uint32_t lane) {
     return p;
 }
 
+// The other way round: which tile of the pixel map (wave index of map_pixel) and which lane own output slot i.
+DEV uint32_t part1by1(uint32_t v) {           // bits of v spread to the even positions (Z-order encode)
+    v &= 0x0000FFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+DEV void slot_to_ray(const PixelMap& pm, size_t i, uint32_t& tile_w, uint32_t& lane) {
+    uint32_t ix, iy;
+    if (pm.mode == 0) {
+        ix = static_cast<uint32_t>(i % static_cast<size_t>(pm.w)); iy = static_cast<uint32_t>(i / static_cast<size_t>(pm.w));
+        tile_w = ((iy >> 7) * pm.super_x + (ix >> 7)) * 256u + (part1by1((ix >> 3) & 15u) | part1by1((iy >> 3) & 15u) << 1);
+    } else {
+        const uint32_t t2 = static_cast<uint32_t>(pm.tile) * static_cast<uint32_t>(pm.tile), wpt_x = static_cast<uint32_t>(pm.tile) / 8u;
+        const uint32_t lt = static_cast<uint32_t>(i / t2), rem = static_cast<uint32_t>(i % t2);
+        ix = rem % static_cast<uint32_t>(pm.tile); iy = rem / static_cast<uint32_t>(pm.tile);
+        tile_w = lt * wpt_x * wpt_x + (iy >> 3) * wpt_x + (ix >> 3);
+    }
+    lane = part1by1(ix & 7u) | part1by1(iy & 7u) << 1;
+}
+
 // ---- counters ------------------------------------------------------------------------------------
 // Wave-level sums, then one atomic per wave and counter into one of RT_CTR_SHARDS cache lines.
 
@@ -927,9 +954,11 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                         if (INST) fb.inst[out] = w.best.inst;
                     }
                 } else {
-                    // only the verdict leaves this kernel: the light's term is evaluated by the resolve kernels, densely
-                    const uint32_t lj = (ridx >> 6) % n_batch;
-                    fb.lit[static_cast<size_t>(out) * RT_LIGHT_BATCH + lj] = w.blocked() ? 0 : 1;
+                    // only the verdict leaves this kernel: the light's term is evaluated by the resolve kernels, densely.
+                    // Verdicts lie in ray order - the 64 rays of a tile towards one light share one 64-byte line - so the
+                    // bytes a swap writes fall into a few lines instead of one line each (per-pixel order cost 16 bytes of
+                    // memory traffic per verdict byte; one bit per ray set with atomics cost 11: atomics go to memory).
+                    fb.lit[ridx] = w.blocked() ? 0 : 1;
                 }
                 state = IDLE;
             }
@@ -951,6 +980,57 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 }
                 return false;
             };
+            // ---- set-up of one fresh ray (index ridx of the launch) in this lane ---------------------------------------
+            auto setup_ray = [&]() {
+                const uint32_t g = ridx >> 6;
+                const Pixel p = map_pixel(pm, MODE == 0 ? g : g / n_batch, ridx & 63u);
+                if (MODE == 1) {
+                    // Everything the new ray needs is asked for at once and unconditionally (slot 0 stands in where the
+                    // lane has no pixel): asking for the surface record only after the id has arrived would put two
+                    // trips to memory one behind the other in every swap.
+                    const uint32_t o = p.valid ? p.out : 0u;
+                    int32_t hid = fb.id[o];
+                    const uint32_t own = fb.slot[o];                                   // with k_surface's marks
+                    const uint32_t own_inst = INST ? fb.inst[o] : REF_NONE;
+                    const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
+                    const float4* entry = (WIDE && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
+                    const rt_light L = sc.lights[light0 + g % n_batch];
+                    asm volatile("" : "+v"(hid));                           // the loads stay up here
+                    RayD r;
+                    bool outward;
+                    const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r, &outward);
+                    if (p.valid && hid >= 0) {
+                        out = o;
+                        w.start(sc, r, deep.e, ld, entry);
+                        // the ray leaves the convex primitive it starts on (k_surface marked it): that one test is a miss
+                        if ((own >> 31) || ((own >> 30) & (outward ? 1u : 0u))) w.set_self(own & 0x0FFFFFFFu, own_inst);
+                        ++n_cast;
+                        state = w.done() ? DONE : TRAV;
+                    }
+                } else if (p.valid) {
+                    out = p.out;
+                    if (MODE == 0) {
+                        RayD r;
+                        bool have = true;
+                        if ((RECORD & 2) && fb.level > 0) {
+                            // a bounce level: the ray was left in the slot by the level above
+                            if (fb.alive[out]) {
+                                r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
+                                r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
+                                r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
+                            } else { have = false; fb.slot[out] = REF_NONE; }
+                        } else {
+                            primary_ray(cam, p.x, p.y, r);
+                        }
+                        if (have) {
+                            const float4* entry = (WIDE && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p + 8u * static_cast<size_t>(g) : nullptr;
+                            w.start(sc, r, deep.e, 0.0, entry);
+                            ++n_cast;
+                            state = w.done() ? DONE : TRAV;
+                        }
+                    }
+                }
+            };
             while (!q_empty) {
                 const unsigned long long idle = __ballot(state == IDLE);
                 if (!idle) break;
@@ -967,54 +1047,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
                 if (state == IDLE && rank < take) {
                     ridx = rank < take_a ? q_next + rank : b_next + (rank - take_a);
-                    const uint32_t g = ridx >> 6;
-                    const Pixel p = map_pixel(pm, MODE == 0 ? g : g / n_batch, ridx & 63u);
-                    if (MODE == 1) {
-                        // Everything the new ray needs is asked for at once and unconditionally (slot 0 stands in where the
-                        // lane has no pixel): asking for the surface record only after the id has arrived would put two
-                        // trips to memory one behind the other in every swap.
-                        const uint32_t o = p.valid ? p.out : 0u;
-                        int32_t hid = fb.id[o];
-                        const uint32_t own = fb.slot[o];                                   // with k_surface's marks
-                        const uint32_t own_inst = INST ? fb.inst[o] : REF_NONE;
-                        const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
-                        const float4* entry = (WIDE && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
-                        const rt_light L = sc.lights[light0 + g % n_batch];
-                        asm volatile("" : "+v"(hid));                           // the loads stay up here
-                        RayD r;
-                        bool outward;
-                        const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r, &outward);
-                        if (p.valid && hid >= 0) {
-                            out = o;
-                            w.start(sc, r, deep.e, ld, entry);
-                            // the ray leaves the convex primitive it starts on (k_surface marked it): that one test is a miss
-                            if ((own >> 31) || ((own >> 30) & (outward ? 1u : 0u))) w.set_self(own & 0x0FFFFFFFu, own_inst);
-                            ++n_cast;
-                            state = w.done() ? DONE : TRAV;
-                        }
-                    } else if (p.valid) {
-                        out = p.out;
-                        if (MODE == 0) {
-                            RayD r;
-                            bool have = true;
-                            if ((RECORD & 2) && fb.level > 0) {
-                                // a bounce level: the ray was left in the slot by the level above
-                                if (fb.alive[out]) {
-                                    r.ox = fb.ray[out]; r.oy = fb.ray[fb.n + out]; r.oz = fb.ray[2*fb.n + out];
-                                    r.dx = fb.ray[3*fb.n + out]; r.dy = fb.ray[4*fb.n + out]; r.dz = fb.ray[5*fb.n + out];
-                                    r.dlen = dsqrt(r.dx*r.dx + r.dy*r.dy + r.dz*r.dz);
-                                } else { have = false; fb.slot[out] = REF_NONE; }
-                            } else {
-                                primary_ray(cam, p.x, p.y, r);
-                            }
-                            if (have) {
-                                const float4* entry = (WIDE && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p + 8u * static_cast<size_t>(g) : nullptr;
-                                w.start(sc, r, deep.e, 0.0, entry);
-                                ++n_cast;
-                                state = w.done() ? DONE : TRAV;
-                            }
-                        }
-                    }
+                    setup_ray();
                 }
                 if (b_end != b_next) { q_next = b_next + take_b; q_end = b_end; } else q_next += take_a;
             }
@@ -1357,13 +1390,15 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
 
 // The terms of the lights of one batch that reach surface point i, added in light order (the reference's accumulation
 // order, raytracer.cpp:210-260) to `lighting`.  view = origin of the ray that found the surface (raytracer.cpp:185-186).
-DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
+DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, const PixelMap& pm, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
                           double vox, double voy, double voz, double lighting) {
     const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
-    const uint2 lit8 = *reinterpret_cast<const uint2*>(fb.lit + i * RT_LIGHT_BATCH);          // the batch's verdicts in one load
-    const unsigned long long lit = static_cast<unsigned long long>(lit8.x) | static_cast<unsigned long long>(lit8.y) << 32;
+    // the slot's verdicts: ray (tile, light j, lane) of the shadow launch wrote byte (tile * n_batch + j) * 64 + lane
+    uint32_t tile_w, lane;
+    slot_to_ray(pm, i, tile_w, lane);
+    const uint8_t* lit = fb.lit + (static_cast<size_t>(tile_w) * n_batch) * 64u + lane;
     for (uint32_t j = 0; j < n_batch; ++j) {
-        if (!((lit >> (8u * j)) & 255u)) continue;
+        if (!lit[64u * j]) continue;
         const rt_light L = sc.lights[light0 + j];
         double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
         lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, vox, voy, voz);
@@ -1373,7 +1408,7 @@ DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, size_t i, uin
 
 // Light terms, then ambient, albedo, gamma.  Lights beyond one batch: the running sum is parked in fb.lighting between
 // batches.
-__global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, FrameBufs fb, uint32_t light0, uint32_t n_batch, int first, int last,
+__global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, uint32_t light0, uint32_t n_batch, int first, int last,
                                                  uint8_t* __restrict__ rgb) {
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= fb.n) return;
@@ -1383,19 +1418,23 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, Fra
         return;
     }
     const rt_mat_rec m = sc.mats[id];
-    const double lighting = add_lit_lights(sc, fb, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], first ? 0.0 : fb.lighting[i]);
+    const double lighting = add_lit_lights(sc, fb, pm, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], first ? 0.0 : fb.lighting[i]);
     if (!last) { fb.lighting[i] = lighting; return; }
     const uint32_t c = finish_shade(m, fb.albedo ? fb.albedo[i] : solid_albedo(m), lighting);
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
 }
 
 // One byte per output slot: bit j set = light j of the batch reaches the slot's surface point; 0 where nothing was hit.
-__global__ void __launch_bounds__(256) k_verdict_mask(FrameBufs fb, uint32_t n_batch, uint8_t* __restrict__ mask) {
+__global__ void __launch_bounds__(256) k_verdict_mask(PixelMap pm, FrameBufs fb, uint32_t n_batch, uint8_t* __restrict__ mask) {
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= fb.n) return;
     uint32_t m = 0;
-    if (fb.id[i] >= 0)
-        for (uint32_t j = 0; j < n_batch; ++j) m |= fb.lit[i * RT_LIGHT_BATCH + j] ? (1u << j) : 0u;
+    if (fb.id[i] >= 0) {
+        uint32_t tile_w, lane;
+        slot_to_ray(pm, i, tile_w, lane);
+        const uint8_t* lit = fb.lit + (static_cast<size_t>(tile_w) * n_batch) * 64u + lane;
+        for (uint32_t j = 0; j < n_batch; ++j) m |= lit[64u * j] ? (1u << j) : 0u;
+    }
     mask[i] = static_cast<uint8_t>(m);
 }
 
@@ -1555,7 +1594,7 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
 // Mirror bounces (trace_ray_recursive, raytracer.cpp:281-371) as a level-by-level pipeline: each level is traced and
 // shadow-tested by the same ray kernels as a plain frame; this kernel closes a level - local colour, Fresnel weight,
 // tint, and the ray of the next level - and k_bounce_fold blends the levels back up once the chain has ended.
-__global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, DevCamera cam, FrameBufs fb, LevelBufs lv, uint32_t light0, uint32_t n_batch, int first, int last,
+__global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, LevelBufs lv, uint32_t light0, uint32_t n_batch, int first, int last,
                                                         int max_scatters, double min_scatter_intensity) {
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= fb.n) return;
@@ -1567,7 +1606,7 @@ __global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, DevCamera c
         const rt_mat_rec m0 = sc.mats[id];
         double vox = cam.pos[0], voy = cam.pos[1], voz = cam.pos[2];
         if (level > 0) { vox = fb.ray[i]; voy = fb.ray[fb.n + i]; voz = fb.ray[2*fb.n + i]; }
-        const double lighting = add_lit_lights(sc, fb, i, light0, n_batch, m0, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
+        const double lighting = add_lit_lights(sc, fb, pm, i, light0, n_batch, m0, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
         if (!last) { fb.lighting[i] = lighting; return; }
         local = finish_shade(m0, fb.albedo ? fb.albedo[i] : solid_albedo(m0), lighting);
     } else if (!last) return;
@@ -1763,16 +1802,16 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, uint32_t light0,
+extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const FrameBufs* fb, uint32_t light0,
                                         uint32_t n_batch, int first, int last, uint8_t* rgb) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
-    if (nb) hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *fb, light0, n_batch, first, last, rgb);
+    if (nb) hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *pm, *fb, light0, n_batch, first, last, rgb);
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_verdict_mask(hipStream_t st, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask) {
+extern "C" hipError_t rt_launch_verdict_mask(hipStream_t st, const PixelMap* pm, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
-    if (nb) hipLaunchKernelGGL(k_verdict_mask, dim3(nb), dim3(256), 0, st, *fb, n_batch, mask);
+    if (nb) hipLaunchKernelGGL(k_verdict_mask, dim3(nb), dim3(256), 0, st, *pm, *fb, n_batch, mask);
     return hipGetLastError();
 }
 
@@ -1819,10 +1858,10 @@ extern "C" hipError_t rt_launch_shade_hits(hipStream_t st, const DevScene* sc, c
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const FrameBufs* fb, const LevelBufs* lv,
+extern "C" hipError_t rt_launch_bounce_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const FrameBufs* fb, const LevelBufs* lv,
                                                uint32_t light0, uint32_t n_batch, int first, int last, int max_scatters, double min_si) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
-    if (nb) hipLaunchKernelGGL(k_bounce_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *fb, *lv, light0, n_batch, first, last, max_scatters, min_si);
+    if (nb) hipLaunchKernelGGL(k_bounce_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *pm, *fb, *lv, light0, n_batch, first, last, max_scatters, min_si);
     return hipGetLastError();
 }
 

@@ -113,3 +113,27 @@ def test_ranks_render_gather_assemble_on_the_gpu(tmp_path, world):
     out = str(tmp_path / "ok.txt")
     mp.spawn(gpu_worker, args=(world, free_port(), out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+
+
+def test_missing_rccl_is_an_error_not_a_crash():
+    """Without a loadable RCCL the exchange entry points return RT_ERR_COMM (-9) with a message; everything else keeps
+    working.  The library binds RCCL once per process, so the miss is forced in a child process."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys\n"
+            "from raytracer_amd import capi\n"
+            "L = capi.lib()\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "rc = L.rt_comm_unique_id(buf)\n"
+            "msg = L.rt_last_error().decode()\n"
+            "assert rc == -9, rc\n"
+            "assert 'RCCL not found' in msg, msg\n"
+            "rc2 = L.rt_comm_unique_id(buf)\n"          # asked again: the same answer, still no crash
+            "assert rc2 == -9, rc2\n"
+            "lut = (C.c_uint8 * 256)()\n"
+            "assert L.rt_gamma_lut(lut) == 0 and lut[255] == 255\n"
+            "print('ok')\n")
+    env = dict(os.environ, RT_RCCL_LIBRARY="/nonexistent/librccl_missing.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
