@@ -2,15 +2,17 @@
 Run from the repository root on the GPU box: PYTHONPATH=. python profiles/tile_share.py"""
 import time
 
+import sys
+
 import torch
 from raytracer_amd import capi, scenes as S
 prims = S.mixed_field(n_side=1000, seed=0x100000)
 lights = S.mixed_field_lights()
-W, H = 3840, 2160
+W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "3840x2160").lower().split("x"))
 cam = capi.make_camera(**S.mixed_field_camera(res=(W, H)))
 ctx = capi.Context(0)
 ctx.upload(capi.Scene.create(prims, lights))
-for tile in (64, 128):
+for tile in (64,):
     for n in (1, 2, 4, 8):
         tiling = capi.Tiling(W, H, tile, n)
         per = capi.tiles_per_rank(tiling) * tile * tile * 3

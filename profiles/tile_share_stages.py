@@ -1,10 +1,12 @@
 """Stage times (HIP events) of one rank's share of the tiled 4K frame, for 1 and 8 ranks: which launch loses when the share is small?
 Run from the repository root on the GPU box: PYTHONPATH=. python profiles/tile_share_stages.py"""
+import sys
+
 import torch
 from raytracer_amd import capi, scenes as S
 prims = S.mixed_field(n_side=1000, seed=0x100000)
 lights = S.mixed_field_lights()
-W, H = 3840, 2160
+W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "3840x2160").lower().split("x"))
 cam = capi.make_camera(**S.mixed_field_camera(res=(W, H)))
 ctx = capi.Context(0)
 ctx.upload(capi.Scene.create(prims, lights))

@@ -543,7 +543,7 @@ int build_on_device(rt_ctx* ctx, const rt_scene* scene) {
     uint8_t* d_need = nullptr;
     size_t work_bytes = 0;
     // wide nodes beside the binary ones (wide node i = inner node i of the binary tree) while their references fit
-    const bool want_wide = n >= 2 && n <= (1u << 27);
+    const bool want_wide = n >= 2 && 2ull * n <= RT_WIDE_NODE_LIMIT;      // wide node i = inner node i: 2n places, addressed by 32-bit byte offsets
     ctx->dev_root_ref = 0; ctx->dev_wide = false;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int rc = RT_OK;

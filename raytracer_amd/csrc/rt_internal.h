@@ -47,6 +47,7 @@ struct rt_inst_rec {
 // fewer entries pushed: peak use is at most (what the collapsed tree needs) + RT_ENTRY_STACK_EXTRA.  Every gate that
 // decides whether a tree may be walked through its wide nodes keeps that margin.
 #define RT_ENTRY_STACK_EXTRA 3
+#define RT_WIDE_NODE_LIMIT (1u << 25) // wide nodes a scene may have: the kernels address them as a 32-bit byte offset (index * 128)
 #define RT_WIDE_STACK_LIMIT (RT_STACK_DEPTH_INST - 1 - RT_ENTRY_STACK_EXTRA)   // largest `need` the wide walk accepts
 #define RT_STACK_DEPTH 32          // traversal stack entries per lane; the builder keeps depth <= 31
 #define RT_MAX_SCATTERS 8

@@ -310,10 +310,17 @@ template <bool FULL, bool UV = false> DEV bool hit_record(const rt_prim_rec* rec
 
 // What a box test needs of a ray.  A plane x = c of the padded box is crossed at t = (c - (o +- pad)) / d, evaluated as
 // one fused multiply-add c * (1/d) + (-(o +- pad) * (1/d)): ix.. are the reciprocals (clamped to +-2^100, so that a ray
-// running along an axis gives huge finite distances of the right sign instead of inf - inf), npx.. / nmx.. the
-// products -(o + pad) / d and -(o - pad) / d.  Rounding: the products carry 2^-24 of |o| / |d|, i.e. |o| 2^-24 along the
-// ray's path - a sixty-fourth of the padding (2^-18 max(|o|, scene radius)), like the other two roundings of the form.
-struct BoxRay { float ix, iy, iz, npx, npy, npz, nmx, nmy, nmz; };
+// running along an axis gives huge finite distances of the right sign instead of inf - inf).  Which of a box's two planes
+// on an axis the ray meets first follows from the sign of the reciprocal alone, so it is decided once per ray: cnx.. is
+// the addend of the plane met first (-(o + pad) / d for the lower plane when d > 0, -(o - pad) / d for the upper one when
+// d < 0: the padding always moves a plane outwards), cfx.. that of the other, and kx.. the byte offset inside a wide node
+// of the vector that holds the four children's first-met planes on that axis (the other plane's vector is at a fixed
+// distance).  The entry distance is then max3 of the near crossings and the exit min3 of the far ones, with no min / max
+// per axis; the values are the ones min / max would pick (a padded box is never thinner than -2 pad).
+// Rounding: the products carry 2^-24 of |o| / |d|, i.e. |o| 2^-24 along the ray's path - a sixty-fourth of the padding
+// (2^-18 max(|o|, scene radius)), like the other two roundings of the form.
+struct BoxRay { float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz; uint32_t kx, ky, kz; };
+constexpr uint32_t WN_LOX = 0u, WN_LOY = 16u, WN_LOZ = 32u, WN_HIX = 48u, WN_HIY = 64u, WN_HIZ = 80u, WN_REF = 96u;   // wide node: byte offsets
 
 DEV float f32_up(double x) {                       // smallest float >= max(x, 0); NaN -> +inf
     if (!(x == x)) return __builtin_inff();
@@ -351,20 +358,28 @@ DEV void box_ray_init(BoxRay& b, const RayD& r, float radius) {
     b.ix = fminf(fmaxf(len / static_cast<float>(r.dx), -big), big);
     b.iy = fminf(fmaxf(len / static_cast<float>(r.dy), -big), big);
     b.iz = fminf(fmaxf(len / static_cast<float>(r.dz), -big), big);
-    b.npx = -(ox + pad) * b.ix; b.npy = -(oy + pad) * b.iy; b.npz = -(oz + pad) * b.iz;
-    b.nmx = -(ox - pad) * b.ix; b.nmy = -(oy - pad) * b.iy; b.nmz = -(oz - pad) * b.iz;
+    const float npx = -(ox + pad) * b.ix, npy = -(oy + pad) * b.iy, npz = -(oz + pad) * b.iz;     // goes with a lower plane
+    const float nmx = -(ox - pad) * b.ix, nmy = -(oy - pad) * b.iy, nmz = -(oz - pad) * b.iz;     // goes with an upper plane
+    const bool fx = b.ix > 0.0f, fy = b.iy > 0.0f, fz = b.iz > 0.0f;                              // lower plane first
+    b.cnx = fx ? npx : nmx; b.cfx = fx ? nmx : npx; b.kx = fx ? WN_LOX : WN_HIX;
+    b.cny = fy ? npy : nmy; b.cfy = fy ? nmy : npy; b.ky = fy ? WN_LOY : WN_HIY;
+    b.cnz = fz ? npz : nmz; b.cfz = fz ? nmz : npz; b.kz = fz ? WN_LOZ : WN_HIZ;
 }
 
-// Entry distance (>= 0) into the padded box, +inf on a miss or when the box starts beyond `limit`.
-DEV float box_entry(const float4 lo, const float4 hi, const BoxRay& b, float limit) {
-    const float ax = __builtin_fmaf(lo.x, b.ix, b.npx), bx = __builtin_fmaf(hi.x, b.ix, b.nmx);
-    const float ay = __builtin_fmaf(lo.y, b.iy, b.npy), by = __builtin_fmaf(hi.y, b.iy, b.nmy);
-    const float az = __builtin_fmaf(lo.z, b.iz, b.npz), bz = __builtin_fmaf(hi.z, b.iz, b.nmz);
-    float tn = fmaxf(0.0f, fminf(ax, bx));
-    float tf = fminf(limit, fmaxf(ax, bx));
-    tn = fmaxf(tn, fminf(ay, by)); tf = fminf(tf, fmaxf(ay, by));
-    tn = fmaxf(tn, fminf(az, bz)); tf = fminf(tf, fmaxf(az, bz));
+// Entry distance (>= 0) into the padded box from its planes in the order the ray meets them, +inf on a miss or when the
+// box starts beyond `limit`.
+DEV float box_entry_ordered(float nx, float ny, float nz, float fx, float fy, float fz, const BoxRay& b, float limit) {
+    const float ax = __builtin_fmaf(nx, b.ix, b.cnx), bx = __builtin_fmaf(fx, b.ix, b.cfx);
+    const float ay = __builtin_fmaf(ny, b.iy, b.cny), by = __builtin_fmaf(fy, b.iy, b.cfy);
+    const float az = __builtin_fmaf(nz, b.iz, b.cnz), bz = __builtin_fmaf(fz, b.iz, b.cfz);
+    const float tn = fmaxf(0.0f, fmaxf(fmaxf(ax, ay), az));
+    const float tf = fminf(limit, fminf(fminf(bx, by), bz));
     return (tn <= tf) ? tn : __builtin_inff();
+}
+// The same for a box given as its corners.
+DEV float box_entry(const float4 lo, const float4 hi, const BoxRay& b, float limit) {
+    const bool fx = b.kx == WN_LOX, fy = b.ky == WN_LOY, fz = b.kz == WN_LOZ;
+    return box_entry_ordered(fx ? lo.x : hi.x, fy ? lo.y : hi.y, fz ? lo.z : hi.z, fx ? hi.x : lo.x, fy ? hi.y : lo.y, fz ? hi.z : lo.z, b, limit);
 }
 
 // A node reference: bits 31..28 = primitive count (0 = internal), bits 27..0 = first slot (leaf) or
@@ -498,7 +513,8 @@ struct Walker {
     // Root box test; afterwards cur is the first node reference or REF_NONE.
     // entry: null, or the entry node of the ray's tile (k_entry): a wide node made for the tile's beam of rays, whose up to
     // four children are the subtrees the beam can touch at all.  The walk then starts with a step on that node.
-    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, const float4* entry = nullptr) {
+    // (given as entry_base + entry_off bytes; entry_base null: none)
+    DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, const char* entry_base = nullptr, uint32_t entry_off = 0) {
         r = ray;
         if (INST) { world_ray_park(ray); inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
@@ -510,7 +526,7 @@ struct Walker {
         limit = (MODE == 0) ? __builtin_inf() : (ldist - 1e-4);
         limit_f = f32_up(limit);
         cur = REF_NONE;
-        if (WIDE && entry) { step_wide<true>(entry); return; }
+        if (WIDE && entry_base) { step_wide<true>(entry_base, entry_off); return; }
         if (WIDE) {
             // the root's box travels with the kernel arguments, with the wide node that holds the root's children
             if (COUNT) vn += 1;
@@ -535,15 +551,24 @@ struct Walker {
 
     // One wide node: 128 contiguous bytes, four boxes.  The children that the ray enters are put in order of their
     // entry distance (a five-exchange sorting network); the walk goes on in the nearest, the others wait on the
-    // stack, farthest pushed first.  An empty place is told by its reference (the slab test orders a box's planes itself,
-    // so an inverted box does not read as a miss); only a tile's entry node (ENTRY) can have its first two places empty.
-    template <bool ENTRY> DEV void step_wide(const float4* n4) {
-        const float4 lox = n4[0], loy = n4[1], loz = n4[2], hix = n4[3], hiy = n4[4], hiz = n4[5], rf = n4[6];
+    // stack, farthest pushed first.  An empty place is told by its reference; only a tile's entry node (ENTRY) can have
+    // its first two places empty.  The node is `off` bytes into `base` (a wave-uniform pointer: scalar base + 32-bit offset).
+    template <bool ENTRY> DEV void step_wide(const char* base, uint32_t off) {
+        // off is a multiple of 128, so the low bits of off + k are k itself and the other plane's vector is one XOR away
+        const uint32_t ax = off + br.kx, ay = off + br.ky, az = off + br.kz;
+        const float4 nx = *reinterpret_cast<const float4*>(base + ax), fx = *reinterpret_cast<const float4*>(base + (ax ^ (WN_LOX ^ WN_HIX)));
+        const float4 ny = *reinterpret_cast<const float4*>(base + ay), fy = *reinterpret_cast<const float4*>(base + (ay ^ (WN_LOY ^ WN_HIY)));
+        const float4 nz = *reinterpret_cast<const float4*>(base + az), fz = *reinterpret_cast<const float4*>(base + (az ^ (WN_LOZ ^ WN_HIZ)));
+        const float4 rf = *reinterpret_cast<const float4*>(base + (off + WN_REF));
+        wide_decide<ENTRY>(nx, fx, ny, fy, nz, fz, rf);
+    }
+    // n*: the four children's planes the ray meets first on each axis, f*: the others; rf: the four references.
+    template <bool ENTRY> DEV void wide_decide(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz, const float4 rf) {
         if (COUNT) vn += 4;
-        float t0 = box_entry(make_float4(lox.x, loy.x, loz.x, 0.0f), make_float4(hix.x, hiy.x, hiz.x, 0.0f), br, limit_f);
-        float t1 = box_entry(make_float4(lox.y, loy.y, loz.y, 0.0f), make_float4(hix.y, hiy.y, hiz.y, 0.0f), br, limit_f);
-        float t2 = box_entry(make_float4(lox.z, loy.z, loz.z, 0.0f), make_float4(hix.z, hiy.z, hiz.z, 0.0f), br, limit_f);
-        float t3 = box_entry(make_float4(lox.w, loy.w, loz.w, 0.0f), make_float4(hix.w, hiy.w, hiz.w, 0.0f), br, limit_f);
+        float t0 = box_entry_ordered(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, br, limit_f);
+        float t1 = box_entry_ordered(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, br, limit_f);
+        float t2 = box_entry_ordered(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, br, limit_f);
+        float t3 = box_entry_ordered(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, br, limit_f);
         uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
         if (ENTRY) {
             t0 = (r0 == REF_NONE) ? __builtin_inff() : t0;
@@ -563,7 +588,7 @@ struct Walker {
 
     // One internal node: fetch both children (64 contiguous bytes), test, descend into the nearer, postpone the other.
     DEV void step_internal(const DevScene& sc) {
-        if (WIDE) { step_wide<false>(sc.nodes4 + 8u * static_cast<size_t>(cur)); return; }
+        if (WIDE) { step_wide<false>(reinterpret_cast<const char*>(sc.nodes4), cur << 7); return; }
         const float4* pair = reinterpret_cast<const float4*>(sc.nodes) + 4u * static_cast<size_t>(cur);
         const float4 llo = pair[0], lhi = pair[1], rlo = pair[2], rhi = pair[3];
         if (COUNT) vn += 2;
@@ -993,7 +1018,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     const uint32_t own = fb.slot[o];                                   // with k_surface's marks
                     const uint32_t own_inst = INST ? fb.inst[o] : REF_NONE;
                     const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
-                    const float4* entry = (WIDE && fb.entry_s) ? fb.entry_s + 8u * static_cast<size_t>(g) : nullptr;   // g = tile * n_batch + light
+                    const char* entry = WIDE ? reinterpret_cast<const char*>(fb.entry_s) : nullptr;    // node g = tile * n_batch + light
                     const rt_light L = sc.lights[light0 + g % n_batch];
                     asm volatile("" : "+v"(hid));                           // the loads stay up here
                     RayD r;
@@ -1001,7 +1026,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r, &outward);
                     if (p.valid && hid >= 0) {
                         out = o;
-                        w.start(sc, r, deep.e, ld, entry);
+                        w.start(sc, r, deep.e, ld, entry, g << 7);
                         // the ray leaves the convex primitive it starts on (k_surface marked it): that one test is a miss
                         if ((own >> 31) || ((own >> 30) & (outward ? 1u : 0u))) w.set_self(own & 0x0FFFFFFFu, own_inst);
                         ++n_cast;
@@ -1023,8 +1048,8 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                             primary_ray(cam, p.x, p.y, r);
                         }
                         if (have) {
-                            const float4* entry = (WIDE && fb.entry_p && !((RECORD & 2) && fb.level > 0)) ? fb.entry_p + 8u * static_cast<size_t>(g) : nullptr;
-                            w.start(sc, r, deep.e, 0.0, entry);
+                            const char* entry = (WIDE && !((RECORD & 2) && fb.level > 0)) ? reinterpret_cast<const char*>(fb.entry_p) : nullptr;
+                            w.start(sc, r, deep.e, 0.0, entry, g << 7);
                             ++n_cast;
                             state = w.done() ? DONE : TRAV;
                         }

@@ -150,7 +150,7 @@ static int finalize_instanced(rt_scene* s, uint32_t max_leaf, uint32_t bins) {
         r.index = k;
         s->inst_recs.push_back(r);
     }
-    if (s->nodes4.size() >= (1ull << 28) || wide_need + 1 + wide_mesh_need >= RT_WIDE_STACK_LIMIT) s->nodes4.clear();
+    if (s->nodes4.size() >= RT_WIDE_NODE_LIMIT || wide_need + 1 + wide_mesh_need >= RT_WIDE_STACK_LIMIT) s->nodes4.clear();
     if (!s->nodes4.empty()) for (rt_inst_rec& r : s->inst_recs) r.root_ref = r.pad[0];
     for (rt_inst_rec& r : s->inst_recs) r.pad[0] = 0;
     s->n_slots = s->recs.size(); s->n_loose = 0; s->loose_boxes.clear();
@@ -250,7 +250,8 @@ int rt_scene_finalize(rt_scene* s, const rt_build_opts* opts) {
     }
     s->nodes.swap(bvh.nodes);
     s->nodes4.clear(); s->wide_root_ref = 0;
-    if (!s->device_build && rt_collapse_wide(s->nodes, s->nodes4) >= RT_WIDE_STACK_LIMIT) s->nodes4.clear();   // too lopsided for the wide walk's stack
+    if (!s->device_build && (rt_collapse_wide(s->nodes, s->nodes4) >= RT_WIDE_STACK_LIMIT || s->nodes4.size() >= RT_WIDE_NODE_LIMIT))
+        s->nodes4.clear();   // too lopsided for the wide walk's stack, or too many nodes for its 32-bit offsets
     s->n_slots = bounded_recs.size();
     s->n_loose = loose.size();
     s->recs.clear(); s->recs.reserve(s->n_slots + s->n_loose);
