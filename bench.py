@@ -359,6 +359,8 @@ def main():
                 break
         # the ceiling of the walk's node fetches: wide nodes per second with every lane on its own L1-resident node
         node_peak = probe["node_per_lane_l1"] * WIDE_NODE_BYTES / 1e9
+        # what the walks read from: binary and wide nodes, primitive records, materials
+        scene_bytes = 32 * int(info.n_nodes) + 128 * int(scene.n_wide()) + 160 * int(info.n_slots + info.n_loose) + 32 * int(info.n_prims)
         ms_mean, ms_sd = mean_sd(step_ms)
         frame_bytes = bytes_primary + bytes_shadow
         device_ms = sum(stage_ms.values())
@@ -376,8 +378,8 @@ def main():
             "config": {
                 "workload": ("%d instances of a %d-triangle mesh (%.1f M triangles, two-level hierarchy), %dx%d, %d mirror bounces, shadow rays to %d point lights"
                              % (info.n_instances, info.n_prims, info.n_instanced_prims / 1e6, W, H, args.max_scatters, len(lights))) if args.instanced else
-                            "1M-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
-                            % (W, H, len(lights)),
+                            "%s-cell mixed primitives (tri/sphere/box + ground plane), %dx%d, primary + shadow rays to %d point lights"
+                            % ("%dM" % round(args.n_side ** 2 / 1e6) if args.n_side >= 1000 else "%dk" % round(args.n_side ** 2 / 1e3), W, H, len(lights)),
                 "n_side": args.n_side, "n_prims": int(info.n_instanced_prims if args.instanced else info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
                 "wide_nodes": (2 * int(info.n_slots) if ctx.build_time_ms() > 0 else scene.n_wide()),
                 "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
@@ -394,19 +396,21 @@ def main():
             "ms_per_step_device": {"mean": ms_mean, "sd": ms_sd, "min": min(step_ms), "max": max(step_ms), "n": len(step_ms),
                                    "what": "HIP events around each step on the kernels' stream (rank 0)"},
             "roofline": {
-                # Bound: the vector-memory request path (texture addresser -> L1), which every node fetch of the walk takes
-                # and which the counters show four fifths busy (profiles/: TA_BUSY), not HBM: most fetches hit L1 / L2.
-                # achieved = ALGORITHMIC bytes of the dominant launch (32 B per box tested, 64 B per primitive record, 9 B per
-                # shadow ray) / its duration from HIP events; peak = the same load sequence measured in this run with
-                # nothing behind it (rt_probe_fetch_rate: every lane its own 128-byte node, table resident in L1).
-                "bound": "l1", "achieved": achieved, "peak": node_peak, "unit": "GB/s", "frac": achieved / node_peak,
-                "peak_source": "measured in this run: rt_probe_fetch_rate(pattern 0, 16 KiB table) x 128 B per wide node",
+                # Bound: HBM by the survey's accounting.  achieved = ALGORITHMIC bytes of the dominant launch (32 B per box
+                # tested, 64 B per primitive record, 9 B per shadow ray) / its duration from HIP events on the kernels' stream;
+                # peak = 8 TB/s.  On a scene that fits the 256 MiB Infinity Cache (n_side 1000: 0.3 GB) most of those bytes are
+                # served by L1 / L2 / MALL and the fraction can exceed 1: `cache_resident` says so, and `hbm_side` gives what
+                # actually crossed the fabric (PMC counters).  --n-side 4000 (5 GB of nodes and records) is the HBM-resident case.
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "cache_resident": bool(scene_bytes < (256 << 20)), "scene_bytes": scene_bytes,
                 # the same launch against HBM itself: what crossed the fabric (PMC counters) per second
-                "hbm": {"achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                        # not a fraction of anything: algorithmic bytes count every fetch, and most are served by caches
-                        "algorithmic_over_peak": achieved / HBM_PEAK_GBS},
+                "hbm_side": {"achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None},
+                # the walk's own load sequence with nothing behind it, measured in this run (rt_probe_fetch_rate: every lane
+                # its own 128-byte node, table resident in L1): what the vector-memory path of a CU can deliver for this pattern
+                "l1_probe": {"achieved": achieved, "peak": node_peak, "unit": "GB/s", "frac": achieved / node_peak,
+                             "peak_source": "measured in this run: rt_probe_fetch_rate(pattern 0, 16 KiB table) x 128 B per wide node"},
                 # the secondary bound: algorithmic flops of the same launch against the FP32 vector peak
                 "fp32": {"achieved": k_flops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": k_flops / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": k_flops},

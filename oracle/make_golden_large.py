@@ -4,6 +4,7 @@
     python oracle/make_golden_large.py config3 [--pixels 65536] [--threads 6]
     python oracle/make_golden_large.py config4 [--pixels 16384]
     python oracle/make_golden_large.py config5 [--pixels 65536]
+    python oracle/make_golden_large.py hbm [--pixels 4096]      (16M cells, 21 M primitives: the working set exceeds every cache)
     python oracle/make_golden_large.py config3_ref_bvh          (needs oracle/_ref: development container only)
 
 config3 / config4: the 1M-cell mixed scene (raytracer_amd/scenes.py::mixed_field, seed 0x100000) at 3840x2160 /
@@ -12,6 +13,9 @@ by the oracle's brute-force loop over ALL 1.33 M primitives in ascending id orde
 algorithm of RayTracer::one_pass_intersection, s2899221/Code/raytracer.cpp:143-157, and of the shadow test in
 RayTracer::shade, raytracer.cpp:210-240); no tree is involved, the product's least of all.  Stored: pixel, closest-hit
 id, FP64 distance, one bit per light (set = the light reaches the point), linear 8-bit colour.
+
+hbm: the same generator with 4000 x 4000 cells (21.3 M primitives, 3.4 GB of records on the device), lights and camera
+scaled with the field as `bench.py --n-side 4000` does, 3840x2160, a seeded sample of pixels, same loop, same fields.
 
 config5: 10 000 instances of a 10 008-triangle mesh, every material a mirror, 3840x2160, two bounces; the oracle's
 loop over all instances and mesh primitives (inst_closest_hit) through rto_trace's recursion.  Stored: pixel, primary
@@ -45,12 +49,13 @@ def sample_pixels(seed, W, H, n):
     return rng.integers(0, W, n).astype(np.uint16), rng.integers(0, H, n).astype(np.uint16)
 
 
-def mixed(name, res, n_pixels, seed, threads):
+def mixed(name, res, n_pixels, seed, threads, n_side=1000):
     W, H = res
     O = bind.Oracle()
-    prims = S.mixed_field(n_side=1000, seed=0x100000)
-    lights = S.mixed_field_lights()
-    camd = S.mixed_field_camera(res=res)
+    half = n_side / 2.0                      # lights and camera scale with the field, as bench.py --n-side does
+    prims = S.mixed_field(n_side=n_side, seed=0x100000)
+    lights = S.mixed_field_lights(half_extent=half, height=120.0 * half / 500.0, intensity=4000.0 * (half / 500.0) ** 2)
+    camd = S.mixed_field_camera(half_extent=half, res=res)
     cam = bind.camera_from_dict(O, camd)
     px, py = sample_pixels(seed, W, H, n_pixels)
     rays = O.pixel_rays(cam, np.stack([px + 0.5, py + 0.5], axis=1))
@@ -66,7 +71,8 @@ def mixed(name, res, n_pixels, seed, threads):
     out = os.path.join(GOLDEN, name + ".npz")
     np.savez_compressed(out, px=px, py=py, id=hits["id"].astype(np.int32), dist=hits["dist"], lit_mask=mask, rgb_linear=rgb,
                         res=np.array(res, dtype=np.int32), pixel_seed=np.array(seed, dtype=np.int64),
-                        n_prims=np.array(len(prims), dtype=np.int64), n_lights=np.array(len(lights), dtype=np.int64))
+                        n_prims=np.array(len(prims), dtype=np.int64), n_lights=np.array(len(lights), dtype=np.int64),
+                        n_side=np.array(n_side, dtype=np.int64))
     print("%s: %d pixels, %d hits, %d lit of %d shadow rays, %.0f s on %d threads -> %s (%d bytes)"
           % (name, n_pixels, int((hits["hit"] == 1).sum()), int(lit.sum()), int((hits["hit"] == 1).sum()) * len(lights), dt, threads,
              out, os.path.getsize(out)))
@@ -122,7 +128,7 @@ def ref_bvh(threads):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["config3", "config4", "config5", "config3_ref_bvh"])
+    ap.add_argument("what", choices=["config3", "config4", "config5", "config3_ref_bvh", "hbm"])
     ap.add_argument("--pixels", type=int, default=0)
     ap.add_argument("--threads", type=int, default=6)
     a = ap.parse_args()
@@ -132,5 +138,7 @@ if __name__ == "__main__":
         mixed("config4_sample", (7680, 4320), a.pixels or 16384, 0xC4, a.threads)
     elif a.what == "config5":
         instanced(a.pixels or 65536, 0xC5, a.threads)
+    elif a.what == "hbm":
+        mixed("hbm_sample", (3840, 2160), a.pixels or 4096, 0xC6, a.threads, n_side=4000)
     else:
         ref_bvh(a.threads)

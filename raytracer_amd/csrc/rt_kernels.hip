@@ -736,6 +736,47 @@ DEV double light_value(const rt_light& L, const rt_mat_rec& m, double px, double
     return attenuation * (diffuse + specular);
 }
 
+// The same term for the dense resolve kernels, in mixed precision.  Positions are of size 10^2..10^3 and what the term
+// depends on are their differences, so L - p and view - p are taken in FP64 and everything after them - normalisations,
+// dot products, the power, the attenuation - runs in FP32 (the result is quantised to 8 bits a few operations later).
+// The power is 2^(e log2 x); its relative error grows with e times the error of x, so exponents above 64 (roughness below
+// 0.174) take the FP64 form above.  Degenerate vectors normalise to (0, 0, 1) as in normalize3.
+#ifndef RT_MIXED_RESOLVE
+#define RT_MIXED_RESOLVE 1
+#endif
+DEV void normalize3f(float x, float y, float z, float& ox, float& oy, float& oz) {
+    const float l2 = x*x + y*y + z*z;
+    if (!(l2 > 1e-30f)) { ox = 0.0f; oy = 0.0f; oz = 1.0f; return; }
+    const float r = __builtin_amdgcn_rsqf(l2);
+    ox = x*r; oy = y*r; oz = z*r;
+}
+// bound: grows by an upper bound of this term's absolute error (attenuation times the relative error of diffuse + specular:
+// a few roundings of 2^-24 each, and e times as much again through the power).
+DEV double light_value_mixed(const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
+                             double nx, double ny, double nz, double view_ox, double view_oy, double view_oz, float& bound) {
+    const float roughness = fminf(fmaxf(static_cast<float>(m.roughness), 0.001f), 1.0f);
+    const float phong_exp = fmaxf(2.0f / (roughness * roughness) - 2.0f, 2.0f);
+    if (phong_exp > 64.0f) {
+        double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);
+        return light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, view_ox, view_oy, view_oz);        // exact: adds nothing to the bound
+    }
+    const float lx = static_cast<float>(L.pos[0] - px), ly = static_cast<float>(L.pos[1] - py), lz = static_cast<float>(L.pos[2] - pz);
+    const float wx = static_cast<float>(view_ox - px), wy = static_cast<float>(view_oy - py), wz = static_cast<float>(view_oz - pz);
+    const float fnx = static_cast<float>(nx), fny = static_cast<float>(ny), fnz = static_cast<float>(nz);
+    const float len2 = lx*lx + ly*ly + lz*lz;
+    const float dist2 = fmaxf(len2, 1e-12f);
+    float dx, dy, dz; normalize3f(lx, ly, lz, dx, dy, dz);
+    float vx, vy, vz; normalize3f(wx, wy, wz, vx, vy, vz);
+    float hx, hy, hz; normalize3f(dx + vx, dy + vy, dz + vz, hx, hy, hz);
+    const float metallic = fminf(fmaxf(static_cast<float>(m.metallic), 0.0f), 1.0f);
+    const float n_dot_l = fmaxf(fnx*dx + fny*dy + fnz*dz, 0.0f);
+    const float n_dot_h = fmaxf(fnx*hx + fny*hy + fnz*hz, 0.0f);
+    const float specular = 0.625f * __builtin_exp2f(phong_exp * __builtin_log2f(n_dot_h));
+    const float attenuation = static_cast<float>(L.intensity) / dist2;
+    bound += __builtin_fabsf(attenuation) * (2e-6f + 4e-7f * phong_exp);
+    return static_cast<double>(attenuation * ((1.0f - metallic) * n_dot_l + specular));
+}
+
 // One light's term of RayTracer::shade (raytracer.cpp:210-260) in one go; 0 when the light is blocked.
 template <bool COUNT, bool INST = false, bool WIDE = false>
 DEV double light_term(const DevScene& sc, const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
@@ -952,6 +993,10 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
     // XCDs): the waves behind one L2 work through neighbouring rays.  A wave whose run is used up helps with the others.
     const uint32_t n_chunks = static_cast<uint32_t>((static_cast<unsigned long long>(n_rays) + RT_CHUNK - 1) / RT_CHUNK);
     uint32_t q_part = blockIdx.x % RT_QUEUE_PARTS, q_tried = 0;
+#ifdef RT_SWAP_TIMING
+    unsigned long long sw_res = 0, sw_fetch = 0, sw_load = 0, sw_comp = 0, sw_n = 0, sw_rays = 0, sw_t = 0;
+    const unsigned long long sw_begin = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef RT_PHASE_TIMING
     unsigned long long pt_swap = 0, pt_inner = 0, pt_leaf = 0, pt_inner_it = 0, pt_inner_lanes = 0, pt_leaf_it = 0, pt_leaf_lanes = 0;
     const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
@@ -965,6 +1010,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
         const int n_done = __popcll(__ballot(state == DONE));
         const bool swap = n_trav == 0 || (q_empty ? n_done >= refill_min : 64 - n_trav >= refill_min);
         if (swap) {
+#ifdef RT_SWAP_TIMING
+            sw_t = __builtin_amdgcn_s_memtime(); sw_n += 1;
+#endif
             // ---- results of finished rays -----------------------------------------------------------------
             if (state == DONE) {
                 if (sc.n_loose) w.finish(sc);
@@ -987,6 +1035,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 }
                 state = IDLE;
             }
+#ifdef RT_SWAP_TIMING
+            { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); sw_res += t - sw_t; sw_t = t; }
+#endif
             // ---- fresh rays for the free lanes ---------------------------------------------------------------
             // next chunk of the wave's run of the chunk sequence (or of the other runs, once that one is used up)
             auto fetch_chunk = [&](uint32_t& c_next, uint32_t& c_end) -> bool {
@@ -1021,6 +1072,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     const char* entry = WIDE ? reinterpret_cast<const char*>(fb.entry_s) : nullptr;    // node g = tile * n_batch + light
                     const rt_light L = sc.lights[light0 + g % n_batch];
                     asm volatile("" : "+v"(hid));                           // the loads stay up here
+#ifdef RT_SWAP_TIMING
+                    { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); sw_load += t - sw_t; sw_t = t; }
+#endif
                     RayD r;
                     bool outward;
                     const double ld = shadow_ray(L, hx, hy, hz, hnx, hny, hnz, r, &outward);
@@ -1068,6 +1122,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                 if (take_a < n_idle && !fetch_chunk(b_next, b_end)) q_empty = true;
                 const uint32_t take_b = n_idle - take_a < b_end - b_next ? n_idle - take_a : b_end - b_next;
                 const uint32_t take = take_a + take_b;
+#ifdef RT_SWAP_TIMING
+                { const unsigned long long t = __builtin_amdgcn_s_memtime(); sw_fetch += t - sw_t; sw_t = t; sw_rays += take; }
+#endif
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
                 if (state == IDLE && rank < take) {
@@ -1075,6 +1132,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     setup_ray();
                 }
                 if (b_end != b_next) { q_next = b_next + take_b; q_end = b_end; } else q_next += take_a;
+#ifdef RT_SWAP_TIMING
+                { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); sw_comp += t - sw_t; sw_t = t; }
+#endif
             }
             if (__ballot(state != IDLE) == 0) { if (q_empty) break; else continue; }
             if (__ballot(state == TRAV) == 0) continue;          // only finished rays on board: write them out first
@@ -1127,6 +1187,18 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
 #endif
     }
     const uint32_t shard = blockIdx.x % RT_CTR_SHARDS;
+#ifdef RT_SWAP_TIMING
+    if (MODE == 1) {
+        const bool l0 = lane == 0;
+        const unsigned long long total = __builtin_amdgcn_s_memtime() - sw_begin;
+        add_counter(ctr, shard, F_VN_P, l0 ? sw_res : 0); add_counter(ctr, shard, F_VP_P, l0 ? sw_fetch : 0);
+        add_counter(ctr, shard, F_VN_S, l0 ? sw_load : 0); add_counter(ctr, shard, F_VP_S, l0 ? sw_comp : 0);
+        add_counter(ctr, shard, F_HITS, l0 ? sw_n : 0); add_counter(ctr, shard, F_BOUNCE, l0 ? total : 0);
+        add_counter(ctr, shard, F_PRIMARY, l0 ? sw_rays : 0);
+        return;
+    }
+    return;
+#endif
 #ifdef RT_PHASE_TIMING
     if (MODE == 1) {
         // wave-level figures: every lane holds its own partial view of the divergent parts; reduce with max
@@ -1415,8 +1487,10 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
 
 // The terms of the lights of one batch that reach surface point i, added in light order (the reference's accumulation
 // order, raytracer.cpp:210-260) to `lighting`.  view = origin of the ray that found the surface (raytracer.cpp:185-186).
+// MIXED: the terms in mixed precision (light_value_mixed), *bound = an upper bound of the sum's absolute error.
+template <bool MIXED = false>
 DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, const PixelMap& pm, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
-                          double vox, double voy, double voz, double lighting) {
+                          double vox, double voy, double voz, double lighting, float* bound = nullptr) {
     const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
     // the slot's verdicts: ray (tile, light j, lane) of the shadow launch wrote byte (tile * n_batch + j) * 64 + lane
     uint32_t tile_w, lane;
@@ -1425,6 +1499,7 @@ DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, const PixelMa
     for (uint32_t j = 0; j < n_batch; ++j) {
         if (!lit[64u * j]) continue;
         const rt_light L = sc.lights[light0 + j];
+        if (MIXED) { lighting += light_value_mixed(L, m, px, py, pz, nx, ny, nz, vox, voy, voz, *bound); continue; }
         double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
         lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, vox, voy, voz);
     }
@@ -1443,9 +1518,33 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, Pix
         return;
     }
     const rt_mat_rec m = sc.mats[id];
-    const double lighting = add_lit_lights(sc, fb, pm, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], first ? 0.0 : fb.lighting[i]);
+    const uint32_t albedo = fb.albedo ? fb.albedo[i] : solid_albedo(m);
+    double lighting;
+    bool exact = true;
+#if RT_MIXED_RESOLVE
+    if (first && last) {
+        // All lights in one batch: the sum in mixed precision first, with a bound on its error.  The colour is
+        // round(intensity * albedo) per channel, so it can only differ from the FP64 result where a channel's product lies
+        // within that error of a half; such pixels (with the bench scene's lights about one in four hundred) are done
+        // again in FP64, every other one has the FP64 colour already.
+        float bound = 0.0f;
+        lighting = add_lit_lights<true>(sc, fb, pm, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], 0.0, &bound);
+        const double metallic = clampd(m.metallic, 0.0, 1.0);
+        double intensity = (1.0 - metallic) * 0.05 + lighting;
+        intensity = intensity < 0.0 ? 0.0 : (intensity > 1.0 ? 1.0 : intensity);
+        const double tol = 1e-4 + 255.0 * static_cast<double>(bound);
+        exact = !(tol < 0.25);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double c = intensity * static_cast<double>((albedo >> (8 * k)) & 255u);
+            const double f = c - __builtin_floor(c);
+            exact = exact || __builtin_fabs(f - 0.5) < tol;
+        }
+    }
+#endif
+    if (exact) lighting = add_lit_lights<false>(sc, fb, pm, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], first ? 0.0 : fb.lighting[i]);
     if (!last) { fb.lighting[i] = lighting; return; }
-    const uint32_t c = finish_shade(m, fb.albedo ? fb.albedo[i] : solid_albedo(m), lighting);
+    const uint32_t c = finish_shade(m, albedo, lighting);
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
 }
 

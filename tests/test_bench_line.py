@@ -25,20 +25,14 @@ def test_bench_prints_one_line_with_roofline_and_cpu_baseline():
     roof = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
-    # the bound is the vector-memory request path (node fetches served by L1 / L2), priced against a rate measured in the
-    # same run; every fraction in the object is a fraction of something: in (0, 1]
-    assert roof["bound"] == "l1" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["kernel_ms"] > 0
-    assert 0.0 < roof["frac"] <= 1.0
-    assert 0.0 < roof["fp32"]["frac"] <= 1.0
-    assert roof["hbm"]["frac"] is None or 0.0 < roof["hbm"]["frac"] <= 1.0
-
-    def fracs(o):
-        for k, v in o.items():
-            if isinstance(v, dict):
-                yield from fracs(v)
-            elif k.endswith("frac") and v is not None:
-                yield v
-    assert all(0.0 < f <= 1.0 for f in fracs(roof))
+    # the bound is HBM, priced with the survey's algorithmic bytes against the 8 TB/s peak; on a scene that fits the
+    # Infinity Cache those bytes are served by caches and the fraction may exceed 1, which the object says itself
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and roof["kernel_ms"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["frac"] > 0.0
+    assert roof["cache_resident"] is True and roof["scene_bytes"] < (256 << 20)
+    # every other fraction in the object is a fraction of something: in (0, 1]
+    assert 0.0 < roof["fp32"]["frac"] <= 1.0 and 0.0 < roof["l1_probe"]["frac"] <= 1.0
+    assert roof["hbm_side"]["frac"] is None or 0.0 < roof["hbm_side"]["frac"] <= 1.0
     dev = d["ms_per_step_device"]
     assert dev["n"] == 3 and dev["sd"] >= 0.0 and dev["min"] <= dev["mean"] <= dev["max"]
     # value = rays of all kinds per second over the timed frames
