@@ -361,6 +361,7 @@ def main():
         node_peak = probe["node_per_lane_l1"] * WIDE_NODE_BYTES / 1e9
         # what the walks read from: binary and wide nodes, primitive records, materials
         scene_bytes = 32 * int(info.n_nodes) + 128 * int(scene.n_wide()) + 160 * int(info.n_slots + info.n_loose) + 32 * int(info.n_prims)
+        walked_bytes = (128 * int(scene.n_wide()) if scene.n_wide() else 32 * int(info.n_nodes)) + 160 * int(info.n_slots + info.n_loose)
         ms_mean, ms_sd = mean_sd(step_ms)
         frame_bytes = bytes_primary + bytes_shadow
         device_ms = sum(stage_ms.values())
@@ -398,12 +399,16 @@ def main():
             "roofline": {
                 # Bound: HBM by the survey's accounting.  achieved = ALGORITHMIC bytes of the dominant launch (32 B per box
                 # tested, 64 B per primitive record, 9 B per shadow ray) / its duration from HIP events on the kernels' stream;
-                # peak = 8 TB/s.  On a scene that fits the 256 MiB Infinity Cache (n_side 1000: 0.3 GB) most of those bytes are
-                # served by L1 / L2 / MALL and the fraction can exceed 1: `cache_resident` says so, and `hbm_side` gives what
-                # actually crossed the fabric (PMC counters).  --n-side 4000 (5 GB of nodes and records) is the HBM-resident case.
+                # peak = 8 TB/s.  Neighbouring rays share their nodes, so most of those bytes are served by L1 / L2 (and, for a scene
+                # the size of n_side 1000's 0.3 GB, the Infinity Cache) and the quotient can exceed 1: `served_by_caches` says how
+                # much, and `hbm_side` gives what actually crossed the fabric (PMC counters).  --n-side 4000 (4.7 GB of nodes and
+                # records) is the case far beyond every cache.
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "cache_resident": bool(scene_bytes < (256 << 20)), "scene_bytes": scene_bytes,
+                # what the walks read from (wide nodes and primitive records) against the 256 MiB Infinity Cache, and the share of
+                # the algorithmic bytes that never crossed the fabric (served by L1 / L2: neighbouring rays share their nodes)
+                "cache_resident": bool(walked_bytes < (256 << 20)), "walked_bytes": walked_bytes, "scene_bytes": scene_bytes,
+                "served_by_caches": (1.0 - traffic / k_bytes) if traffic and k_bytes else None,
                 # the same launch against HBM itself: what crossed the fabric (PMC counters) per second
                 "hbm_side": {"achieved": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None},

@@ -38,5 +38,22 @@ def main(tag, out):
         shutil.copy(tj, os.path.join(ROOT, "profiles", tag + "_traffic.json"))      # made on the box, before the bench line
 
 
+def extra(out):
+    """The bench lines and kernel stats of collect_r3_extra.sh."""
+    raw = os.path.join(ROOT, "gpurun_out", "r3_extra")
+    out = os.path.join(ROOT, out)
+    for tag, name in (("inst", "instanced"), ("devbuild", "device_build")):
+        src = os.path.join(raw, tag, tag + "_kernel_stats.csv")
+        if os.path.exists(src):
+            stats(src, os.path.join(out, "kernel_stats_%s.csv" % name))
+    for name in ("inst_bench.json", "devbuild_bench.json", "res8k_bench.json", "bounce2_bench.json", "config2.json"):
+        if os.path.exists(os.path.join(raw, name)):
+            lines = open(os.path.join(raw, name)).read().strip().splitlines()
+            open(os.path.join(out, name), "w").write(lines[-1] + "\n")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == "extra":
+        extra(sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2])

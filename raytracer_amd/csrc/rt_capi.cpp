@@ -63,6 +63,7 @@ struct rt_ctx {
     void* static_scratch = nullptr;        // this GPU's copy of the library's fixed workspace (rt_render_rect_static)
     size_t static_scratch_bytes = 0;
     uint32_t max_waves = 4096;             // persistent waves per launch: CUs x resident waves per CU
+    uint32_t wave_div = 8;                 // a launch gets one wave per wave_div groups of 64 rays (RT_WAVE_DIV; experiments)
     int refill_env = 0;                    // RT_REFILL_MIN from the environment (experiments); 0: the defaults below
     // free lanes a persistent wave lets pile up before it swaps rays: walks through instances pay more per swap
     // (100M-triangle frame at 32 / 40 / 48: 22.2 / 21.7 / 21.4 ms; one-level scenes are best at 32)
@@ -400,6 +401,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
             int per_cu = 16;                                   // 4 waves per SIMD at <= 128 VGPRs
             if (const char* env = std::getenv("RT_WAVES_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 32) per_cu = v; }
             c->max_waves = static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu;
+            if (const char* env = std::getenv("RT_MAX_WAVES")) { const long v = std::atol(env); if (v >= 64 && v <= (1l << 24)) c->max_waves = static_cast<uint32_t>(v); }
+            if (const char* env = std::getenv("RT_WAVE_DIV")) { const int v = std::atoi(env); if (v >= 1 && v <= 1024) c->wave_div = static_cast<uint32_t>(v); }
             if (const char* env = std::getenv("RT_ENTRY_SEARCH")) c->entry_search = std::atoi(env) != 0;
             if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_env = v; }
         }
@@ -715,7 +718,7 @@ int next_queue(rt_ctx* ctx, QueueBlock& qb, unsigned int** q) {
 // lane about eight rays to walk - a small launch (one rank's share of a tiled frame) otherwise spends most of its time
 // in the ramp and the tail of waves that carry three or four rays per lane.
 uint32_t wave_count(const rt_ctx* ctx, uint64_t n_tiles) {
-    uint64_t want = n_tiles / 8u;
+    uint64_t want = n_tiles / ctx->wave_div;
     if (want < 256u) want = n_tiles < 256u ? (n_tiles ? n_tiles : 1u) : 256u;
     return static_cast<uint32_t>(want < ctx->max_waves ? want : ctx->max_waves);
 }
@@ -753,7 +756,8 @@ int frame_bufs(rt_ctx* ctx, size_t n, uint32_t n_batch, size_t n_tiles, FrameBuf
     void* base = nullptr;
     const size_t fbytes = (frame_bytes(n) + 255u) & ~static_cast<size_t>(255);
     const size_t vbytes = (verdict_bytes(n_tiles, n_batch) + 255u) & ~static_cast<size_t>(255);
-    const bool entry = wants_entry_search(ctx);
+    // entry nodes are addressed by 32-bit byte offsets (128 bytes each): a frame with more beams goes without the search
+    const bool entry = wants_entry_search(ctx) && static_cast<uint64_t>(n_tiles) * n_batch < RT_WIDE_NODE_LIMIT;
     if (int rc = ctx->need(3, fbytes + vbytes + (entry ? tile_bytes(n_tiles, n_batch) : 0), &base)) return rc;
     carve_frame(base, n, ctx->sc.n_textures != 0, fb);
     fb.lit = static_cast<uint8_t*>(base) + fbytes;

@@ -29,7 +29,8 @@ def test_bench_prints_one_line_with_roofline_and_cpu_baseline():
     # Infinity Cache those bytes are served by caches and the fraction may exceed 1, which the object says itself
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and roof["kernel_ms"] > 0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["frac"] > 0.0
-    assert roof["cache_resident"] is True and roof["scene_bytes"] < (256 << 20)
+    assert roof["cache_resident"] is True and roof["walked_bytes"] <= roof["scene_bytes"] < (256 << 20)
+    assert roof["served_by_caches"] is None or 0.0 <= roof["served_by_caches"] < 1.0
     # every other fraction in the object is a fraction of something: in (0, 1]
     assert 0.0 < roof["fp32"]["frac"] <= 1.0 and 0.0 < roof["l1_probe"]["frac"] <= 1.0
     assert roof["hbm_side"]["frac"] is None or 0.0 < roof["hbm_side"]["frac"] <= 1.0
