@@ -1,0 +1,9 @@
+# usage: bash exp/sweep.sh VARIANT...: bench stage times of each variant library (base = the regular one), 2 runs each
+for V in "$@"; do
+  if [ "$V" = base ]; then LIBV=""; else LIBV="exp/librt_hip_$V.so"; fi
+  for R in 1 2; do
+  RT_HIP_LIB=$LIBV timeout -k 10 120 python bench.py --steps 10 --warmup 3 --cpu-seconds 0 > gpurun_out/sw_$V.json 2> gpurun_out/sw_$V.err || { echo "bench $V failed"; tail -3 gpurun_out/sw_$V.err; exit 1; }
+  python -c "
+import json;d=json.load(open('gpurun_out/sw_$V.json'));r=d['roofline'];print('$V', round(d['ms_per_step'],3),{k:round(v,3) for k,v in r['stage_ms_per_frame'].items()},round(r['nodes_per_primary_ray'],2),round(r['nodes_per_shadow_ray'],2))"
+  done
+done

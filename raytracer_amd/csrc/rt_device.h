@@ -18,6 +18,9 @@
 #ifndef RT_CHUNK
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
 #endif
+#ifndef RT_CHUNK_PRIMARY
+#define RT_CHUNK_PRIMARY 512u      // the same for the camera rays of a plain frame
+#endif
 #define RT_REFILL_MIN 32           // finished lanes that must pile up before a wave swaps rays (default)
 #define RT_REFILL_MIN_INST 48      // the same for two-level scenes
 // per 8x8 tile: one 128-byte entry node for its camera rays, one per light of a batch for its shadow rays, and the box of
