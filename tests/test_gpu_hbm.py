@@ -4,7 +4,8 @@ of records, 1.3 GB of wide nodes on the device), 3840x2160, four lights - `bench
 Fixture: tests/golden/hbm_sample.npz (oracle/make_golden_large.py hbm, made in the development container): 4 096 seeded
 pixels, every primary ray and every shadow ray cast from its hit resolved by the oracle's loop over ALL primitives in
 ascending id order - no tree of anyone's.  Checked: ids and FP64 distance bits equal, one verdict bit per light equal,
-colour within +-1; the frame's counters agree with its id plane; eight virtual ranks' tiles reproduce the single launch."""
+colour within +-1; the frame's counters agree with its id plane; a rank's tiles reproduce the single launch; the frame
+through a hierarchy built on the device equals the frame through the host's."""
 import os
 
 import numpy as np
@@ -78,5 +79,14 @@ def test_sixteen_million_cells_4k():
             x0, y0 = (t % tiles_x) * 64, (t // tiles_x) * 64
             h, w = min(64, H - y0), min(64, W - x0)
             assert np.array_equal(tiles[lt, :h, :w], rgb[y0:y0 + h, x0:x0 + w])
+        # the hierarchy built on the device for the same primitives (beyond 16.7 M of them its wide form is not made:
+        # wide node i = inner node i would pass the 2^25 nodes the kernels can address, so the binary nodes are walked):
+        # results do not depend on whose tree it is
+        sc = None
+        dev = capi.Scene.create(prims, lights, on_device=True)
+        ctx.upload(dev)
+        assert ctx.build_time_ms() > 0.0
+        rgb2, ids2 = ctx.render(cam, max_scatters=0, want_ids=True)
+        assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
     finally:
         ctx.close()
