@@ -1508,29 +1508,19 @@ DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, const PixelMa
     return lighting;
 }
 
-// Light terms, then ambient, albedo, gamma.  Lights beyond one batch: the running sum is parked in fb.lighting between
-// batches.
-__global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, uint32_t light0, uint32_t n_batch, int first, int last,
-                                                 uint8_t* __restrict__ rgb) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= fb.n) return;
-    const int32_t id = fb.id[i];
-    if (id < 0) {
-        if (last) { rgb[i*3] = sc.gamma[0]; rgb[i*3 + 1] = sc.gamma[0]; rgb[i*3 + 2] = sc.gamma[0]; }
-        return;
-    }
-    const rt_mat_rec m = sc.mats[id];
-    const uint32_t albedo = fb.albedo ? fb.albedo[i] : solid_albedo(m);
-    double lighting;
+// The light sum of slot i after this batch, for the resolve kernels.  When the batch holds all the lights the sum is made
+// in mixed precision first, with a bound on its error: the colour is round(intensity * albedo) per channel, so it can
+// only differ from the FP64 result where a channel's product lies within that error of a half; such slots (with the
+// bench scene's lights about one in four hundred) are summed again in FP64, every other one has the FP64 colour already.
+// Several batches: FP64 throughout (the running sum waits in fb.lighting).
+DEV double resolve_lighting(const DevScene& sc, const FrameBufs& fb, const PixelMap& pm, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
+                            uint32_t albedo, double vox, double voy, double voz, int first, int last) {
     bool exact = true;
+    double lighting = 0.0;
 #if RT_MIXED_RESOLVE
     if (first && last) {
-        // All lights in one batch: the sum in mixed precision first, with a bound on its error.  The colour is
-        // round(intensity * albedo) per channel, so it can only differ from the FP64 result where a channel's product lies
-        // within that error of a half; such pixels (with the bench scene's lights about one in four hundred) are done
-        // again in FP64, every other one has the FP64 colour already.
         float bound = 0.0f;
-        lighting = add_lit_lights<true>(sc, fb, pm, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], 0.0, &bound);
+        lighting = add_lit_lights<true>(sc, fb, pm, i, light0, n_batch, m, vox, voy, voz, 0.0, &bound);
         const double metallic = clampd(m.metallic, 0.0, 1.0);
         double intensity = (1.0 - metallic) * 0.05 + lighting;
         intensity = intensity < 0.0 ? 0.0 : (intensity > 1.0 ? 1.0 : intensity);
@@ -1544,7 +1534,24 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, Pix
         }
     }
 #endif
-    if (exact) lighting = add_lit_lights<false>(sc, fb, pm, i, light0, n_batch, m, cam.pos[0], cam.pos[1], cam.pos[2], first ? 0.0 : fb.lighting[i]);
+    if (exact) lighting = add_lit_lights<false>(sc, fb, pm, i, light0, n_batch, m, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
+    return lighting;
+}
+
+// Light terms, then ambient, albedo, gamma.  Lights beyond one batch: the running sum is parked in fb.lighting between
+// batches.
+__global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, uint32_t light0, uint32_t n_batch, int first, int last,
+                                                 uint8_t* __restrict__ rgb) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= fb.n) return;
+    const int32_t id = fb.id[i];
+    if (id < 0) {
+        if (last) { rgb[i*3] = sc.gamma[0]; rgb[i*3 + 1] = sc.gamma[0]; rgb[i*3 + 2] = sc.gamma[0]; }
+        return;
+    }
+    const rt_mat_rec m = sc.mats[id];
+    const uint32_t albedo = fb.albedo ? fb.albedo[i] : solid_albedo(m);
+    const double lighting = resolve_lighting(sc, fb, pm, i, light0, n_batch, m, albedo, cam.pos[0], cam.pos[1], cam.pos[2], first, last);
     if (!last) { fb.lighting[i] = lighting; return; }
     const uint32_t c = finish_shade(m, albedo, lighting);
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
@@ -1732,9 +1739,10 @@ __global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, DevCamera c
         const rt_mat_rec m0 = sc.mats[id];
         double vox = cam.pos[0], voy = cam.pos[1], voz = cam.pos[2];
         if (level > 0) { vox = fb.ray[i]; voy = fb.ray[fb.n + i]; voz = fb.ray[2*fb.n + i]; }
-        const double lighting = add_lit_lights(sc, fb, pm, i, light0, n_batch, m0, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
+        const uint32_t albedo0 = fb.albedo ? fb.albedo[i] : solid_albedo(m0);
+        const double lighting = resolve_lighting(sc, fb, pm, i, light0, n_batch, m0, albedo0, vox, voy, voz, first, last);
         if (!last) { fb.lighting[i] = lighting; return; }
-        local = finish_shade(m0, fb.albedo ? fb.albedo[i] : solid_albedo(m0), lighting);
+        local = finish_shade(m0, albedo0, lighting);
     } else if (!last) return;
     lv.local[static_cast<size_t>(level) * fb.n + i] = local;
     lv.last[i] = static_cast<uint8_t>(level);
