@@ -568,13 +568,9 @@ struct Walker {
         float t1 = box_entry_ordered(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, br, limit_f);
         float t2 = box_entry_ordered(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, br, limit_f);
         float t3 = box_entry_ordered(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, br, limit_f);
+        // an empty place holds an inverted box (lower planes at +inf, upper at -inf: every builder and the entry search write
+        // it so), which the ordered test cannot enter: its near crossings are +inf and its far ones -inf whatever the ray
         uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
-        if (ENTRY) {
-            t0 = (r0 == REF_NONE) ? __builtin_inff() : t0;
-            t1 = (r1 == REF_NONE) ? __builtin_inff() : t1;
-        }
-        t2 = (r2 == REF_NONE) ? __builtin_inff() : t2;
-        t3 = (r3 == REF_NONE) ? __builtin_inff() : t3;
 #define RT_EXCHANGE(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; \
                                       const uint32_t rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
         RT_EXCHANGE(t0, r0, t1, r1) RT_EXCHANGE(t2, r2, t3, r3) RT_EXCHANGE(t0, r0, t2, r2) RT_EXCHANGE(t1, r1, t3, r3) RT_EXCHANGE(t1, r1, t2, r2)
@@ -1420,7 +1416,11 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
         // the set: four places, each a reference and its box (REF_NONE = empty place); `closed` marks places whose
         // subtree cannot be refined at present because its touched children would not fit
         uint32_t ref[4] = { REF_NONE, REF_NONE, REF_NONE, REF_NONE };
-        float blo[4][3] = {}, bhi[4][3] = {};
+        float blo[4][3], bhi[4][3];                          // an empty place keeps an inverted box: the walks rely on it
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { blo[k][a] = __builtin_inff(); bhi[k][a] = -__builtin_inff(); }
         uint32_t closed = 0;
         if (any) {
             vn += 1;
@@ -1459,7 +1459,12 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
             }
             if (count - 1u + nh > 4u) { closed |= 1u << pick; continue; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (k == pick) ref[k] = REF_NONE;
+            for (int k = 0; k < 4; ++k)
+                if (k == pick) {
+                    ref[k] = REF_NONE;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { blo[k][a] = __builtin_inff(); bhi[k][a] = -__builtin_inff(); }
+                }
             if (nh == 0) closed = 0;                              // a place came free: the others get another chance
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
