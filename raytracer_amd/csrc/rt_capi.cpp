@@ -156,6 +156,7 @@ int rect_map(const rt_camera* cam, rt_rect r, PixelMap& pm, uint32_t& n_blocks) 
     const uint64_t nb = static_cast<uint64_t>(pm.super_x) * ((static_cast<uint32_t>(r.h) + 127u) / 128u) * 256u;
     if (nb * 64u * RT_LIGHT_BATCH >= 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "rectangle too large for one launch");
     n_blocks = static_cast<uint32_t>(nb);      // waves: one 8x8 tile each
+    pixel_map_divisors(pm);
     return RT_OK;
 }
 
@@ -1110,6 +1111,7 @@ int rt_render_tiles(rt_ctx* ctx, const rt_camera* cam, rt_tiling tiling, int ran
     pm.mode = 1; pm.w = tiling.width; pm.h = tiling.height; pm.tile = tiling.tile;
     pm.tiles_x = (tiling.width + tiling.tile - 1) / tiling.tile;
     pm.n_tiles = rt_tile_count(tiling); pm.rank = rank; pm.n_ranks = tiling.n_ranks;
+    pixel_map_divisors(pm);
     const uint32_t wpt = static_cast<uint32_t>(tiling.tile / 8) * static_cast<uint32_t>(tiling.tile / 8);
     const uint64_t nw64 = static_cast<uint64_t>(per_rank) * wpt;
     if (nw64 * 64u * RT_LIGHT_BATCH >= 0xFFFFFFFFull) return fail(RT_ERR_LIMIT, "too many tiles for one launch");

@@ -64,12 +64,30 @@ struct DevCamera {                 // persp_camera.h:29-36 with the sensor-fit b
 //   mode 0: rectangle (x0, y0, w, h) of the frame, output row-major in the rectangle;
 //           super_x = 128x128-pixel super tiles per row (256 waves each).
 //   mode 1: this rank's tiles of a tiled frame (w, h = frame size, x0 = y0 = 0); output tile after tile.
+// A divisor fixed for a launch: n / d is umulhi(n, m) with m = ceil(2^32 / d) (m = 0 stands for d = 1), which exceeds the
+// quotient by one at most for any n < 2^32; one multiply-subtract tells (the kernels' div_by).  The compiler's own
+// division by a run-time value is twenty instructions, and the pixel maps are evaluated for every ray that is set up.
+struct DivU32 { uint32_t d, m; };
+inline DivU32 make_div_u32(uint32_t d) { DivU32 k; k.d = d; k.m = d > 1u ? static_cast<uint32_t>((1ull << 32) / d) + (((1ull << 32) % d) ? 1u : 0u) : 0u; return k; }
+
 struct PixelMap {
     int mode;
     int x0, y0, w, h;
     uint32_t super_x;
     int tile, tiles_x, n_tiles, rank, n_ranks;
+    // the divisors the maps use (pixel_map_divisors): super_x, w | waves per tile, tiles_x, waves per tile row, tile^2, tile
+    DivU32 d_super_x, d_w, d_wpt, d_tiles_x, d_wpt_x, d_t2, d_tile;
 };
+inline void pixel_map_divisors(PixelMap& pm) {
+    pm.d_super_x = make_div_u32(pm.super_x ? pm.super_x : 1u);
+    pm.d_w = make_div_u32(pm.w > 0 ? static_cast<uint32_t>(pm.w) : 1u);
+    const uint32_t tile = pm.tile > 0 ? static_cast<uint32_t>(pm.tile) : 8u, wpt_x = tile / 8u ? tile / 8u : 1u;
+    pm.d_wpt = make_div_u32(wpt_x * wpt_x);
+    pm.d_tiles_x = make_div_u32(pm.tiles_x > 0 ? static_cast<uint32_t>(pm.tiles_x) : 1u);
+    pm.d_wpt_x = make_div_u32(wpt_x);
+    pm.d_t2 = make_div_u32(tile * tile);
+    pm.d_tile = make_div_u32(tile);
+}
 
 // Per-frame working set of the frame pipeline (closest hit, surface records, shadow verdicts, resolve) (all planes have n entries, indexed by output slot).
 struct FrameBufs {

@@ -885,6 +885,16 @@ DEV uint32_t xcd_contiguous(uint32_t b, uint32_t nb) {
 
 struct Pixel { int x, y; uint32_t out; bool valid; };
 
+// n / k.d, remainder in rem (DivU32 in rt_device.h).
+DEV uint32_t div_by(uint32_t n, const DivU32 k, uint32_t& rem) {
+    uint32_t q = k.m ? __umulhi(n, k.m) : n;
+    int32_t r = static_cast<int32_t>(n - q * k.d);
+    if (r < 0) { --q; r += static_cast<int32_t>(k.d); }
+    rem = static_cast<uint32_t>(r);
+    return q;
+}
+DEV DivU32 make_div(uint32_t d) { DivU32 k; k.d = d; k.m = d > 1u ? (0xFFFFFFFFu / d) + 1u : 0u; return k; }     // ceil(2^32 / d) = floor((2^32 - 1) / d) + 1
+
 // Wave `w` of the pixel map owns one 8x8 tile, lanes in Z-order.  Rectangle mode: waves run in Z-order inside
 // 128x128-pixel super tiles.  Tile mode: a rank's tiles one after the other, 8x8 blocks row-major inside a tile.
 DEV Pixel map_pixel(const PixelMap& pm, uint32_t w, uint32_t lane) {
@@ -892,20 +902,23 @@ DEV Pixel map_pixel(const PixelMap& pm, uint32_t w, uint32_t lane) {
     Pixel p; p.valid = false; p.x = 0; p.y = 0; p.out = 0;
     if (pm.mode == 0) {
         const uint32_t st = w >> 8, in = w & 255u;
-        const int rx = static_cast<int>((st % pm.super_x) * 128u + compact1by1(in) * 8u) + lx;
-        const int ry = static_cast<int>((st / pm.super_x) * 128u + compact1by1(in >> 1) * 8u) + ly;
+        uint32_t sx;
+        const uint32_t sy = div_by(st, pm.d_super_x, sx);
+        const int rx = static_cast<int>(sx * 128u + compact1by1(in) * 8u) + lx;
+        const int ry = static_cast<int>(sy * 128u + compact1by1(in >> 1) * 8u) + ly;
         if (rx < pm.w && ry < pm.h) {
             p.valid = true; p.x = pm.x0 + rx; p.y = pm.y0 + ry;
             p.out = static_cast<uint32_t>(ry) * static_cast<uint32_t>(pm.w) + static_cast<uint32_t>(rx);
         }
     } else {
-        const uint32_t wpt_x = static_cast<uint32_t>(pm.tile) / 8u, wpt = wpt_x * wpt_x;
-        const uint32_t lt = w / wpt, in = w % wpt;
+        uint32_t in;
+        const uint32_t lt = div_by(w, pm.d_wpt, in);
         const uint32_t gt = lt * static_cast<uint32_t>(pm.n_ranks) + static_cast<uint32_t>(pm.rank);
         if (gt < static_cast<uint32_t>(pm.n_tiles)) {
-            const int tx = static_cast<int>(gt % static_cast<uint32_t>(pm.tiles_x)) * pm.tile;
-            const int ty = static_cast<int>(gt / static_cast<uint32_t>(pm.tiles_x)) * pm.tile;
-            const int ix = static_cast<int>(in % wpt_x) * 8 + lx, iy = static_cast<int>(in / wpt_x) * 8 + ly;
+            uint32_t gx, bx;
+            const uint32_t gy = div_by(gt, pm.d_tiles_x, gx), by = div_by(in, pm.d_wpt_x, bx);
+            const int tx = static_cast<int>(gx) * pm.tile, ty = static_cast<int>(gy) * pm.tile;
+            const int ix = static_cast<int>(bx) * 8 + lx, iy = static_cast<int>(by) * 8 + ly;
             if (tx + ix < pm.w && ty + iy < pm.h) {
                 p.valid = true; p.x = pm.x0 + tx + ix; p.y = pm.y0 + ty + iy;
                 p.out = lt * static_cast<uint32_t>(pm.tile * pm.tile) + static_cast<uint32_t>(iy * pm.tile + ix);
@@ -926,14 +939,16 @@ DEV uint32_t part1by1(uint32_t v) {           // bits of v spread to the even po
 }
 DEV void slot_to_ray(const PixelMap& pm, size_t i, uint32_t& tile_w, uint32_t& lane) {
     uint32_t ix, iy;
+    // output slots are 32-bit throughout (a launch holds fewer than 2^32 / 64 / RT_LIGHT_BATCH tiles)
     if (pm.mode == 0) {
-        ix = static_cast<uint32_t>(i % static_cast<size_t>(pm.w)); iy = static_cast<uint32_t>(i / static_cast<size_t>(pm.w));
+        iy = div_by(static_cast<uint32_t>(i), pm.d_w, ix);
         tile_w = ((iy >> 7) * pm.super_x + (ix >> 7)) * 256u + (part1by1((ix >> 3) & 15u) | part1by1((iy >> 3) & 15u) << 1);
     } else {
-        const uint32_t t2 = static_cast<uint32_t>(pm.tile) * static_cast<uint32_t>(pm.tile), wpt_x = static_cast<uint32_t>(pm.tile) / 8u;
-        const uint32_t lt = static_cast<uint32_t>(i / t2), rem = static_cast<uint32_t>(i % t2);
-        ix = rem % static_cast<uint32_t>(pm.tile); iy = rem / static_cast<uint32_t>(pm.tile);
-        tile_w = lt * wpt_x * wpt_x + (iy >> 3) * wpt_x + (ix >> 3);
+        const uint32_t wpt_x = pm.d_wpt_x.d;
+        uint32_t rem;
+        const uint32_t lt = div_by(static_cast<uint32_t>(i), pm.d_t2, rem);
+        iy = div_by(rem, pm.d_tile, ix);
+        tile_w = lt * pm.d_wpt.d + (iy >> 3) * wpt_x + (ix >> 3);
     }
     lane = part1by1(ix & 7u) | part1by1(iy & 7u) << 1;
 }
@@ -977,6 +992,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                                              FrameBufs fb, rt_counters* ctr, unsigned int* queue, int refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_batch = MODE == 1 ? (n_rays >> 6) / n_tiles : 1u;      // lights of this shadow launch
+    const DivU32 d_batch = make_div(n_batch);
     enum { IDLE = 0, TRAV = 1, DONE = 2 };
     uint32_t state = IDLE, out = 0, ridx = 0;
     Walker<MODE, COUNT, INST, WIDE> w; w.vn = 0; w.vp = 0; w.cur = REF_NONE;
@@ -1057,7 +1073,9 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
             // ---- set-up of one fresh ray (index ridx of the launch) in this lane ---------------------------------------
             auto setup_ray = [&]() {
                 const uint32_t g = ridx >> 6;
-                const Pixel p = map_pixel(pm, MODE == 0 ? g : g / n_batch, ridx & 63u);
+                uint32_t g_light = 0;                            // MODE 1: the light of the ray's group within the batch
+                const uint32_t g_tile = MODE == 0 ? g : div_by(g, d_batch, g_light);
+                const Pixel p = map_pixel(pm, g_tile, ridx & 63u);
                 if (MODE == 1) {
                     // Everything the new ray needs is asked for at once and unconditionally (slot 0 stands in where the
                     // lane has no pixel): asking for the surface record only after the id has arrived would put two
@@ -1068,7 +1086,7 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     const uint32_t own_inst = INST ? fb.inst[o] : REF_NONE;
                     const double hx = fb.px[o], hy = fb.py[o], hz = fb.pz[o], hnx = fb.nx[o], hny = fb.ny[o], hnz = fb.nz[o];
                     const char* entry = WIDE ? reinterpret_cast<const char*>(fb.entry_s) : nullptr;    // node g = tile * n_batch + light
-                    const rt_light L = sc.lights[light0 + g % n_batch];
+                    const rt_light L = sc.lights[light0 + g_light];
                     asm volatile("" : "+v"(hid));                           // the loads stay up here
 #ifdef RT_SWAP_TIMING
                     { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); sw_load += t - sw_t; sw_t = t; }
