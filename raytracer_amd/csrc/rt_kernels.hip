@@ -397,23 +397,28 @@ template <bool BIG> struct DeepStack { uint2 e[(BIG ? RT_STACK_DEPTH_INST : RT_S
 __shared__ uint2 g_lds_stack[RT_STACK_LDS * 64];
 struct Stack {
     uint2* deep;                      // DeepStack::e of the owning kernel
-    uint32_t lane;                    // this lane's column of g_lds_stack
-    uint32_t sp;
+    // Where the next entry goes, as the byte offset it would have in the LDS part: entries * 512 + lane * 8 (a row of 64
+    // entries is 512 bytes and a lane's column starts below that, so entries = top >> 9 and "none" is top < 512).
+    // Kept in this form a push or pop costs one addition, not a shift and an addition.
+    uint32_t top;
+    DEV void reset(uint32_t lane) { top = lane * 8u; }
     DEV void push(uint32_t ref, float t) {
         const uint2 e = make_uint2(ref, __float_as_uint(t));
-        if (sp < RT_STACK_LDS) g_lds_stack[sp * 64u + lane] = e; else deep[sp - RT_STACK_LDS] = e;
-        ++sp;
+        if (top < RT_STACK_LDS * 512u) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(g_lds_stack) + top) = e;
+        else deep[(top >> 9) - RT_STACK_LDS] = e;
+        top += 512u;
     }
     // next entry that still starts before `limit`, or REF_NONE
     DEV uint32_t pop(float limit) {
-        while (sp) {
-            --sp;
+        while (top >= 512u) {
+            top -= 512u;
             // an LDS read in any case (of a clamped slot), replaced from the private part when the entry lives there:
             // left to itself the compiler picks between the two addresses and reads through one flat load, which is
             // much slower than ds_read
-            uint2 e = g_lds_stack[(sp < RT_STACK_LDS ? sp : RT_STACK_LDS - 1u) * 64u + lane];
+            const uint32_t at = top < RT_STACK_LDS * 512u ? top : (RT_STACK_LDS - 1u) * 512u + (top & 511u);
+            uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(g_lds_stack) + at);
             asm volatile("" : "+v"(e.x), "+v"(e.y));          // keeps the read where it is, as a ds_read
-            if (sp >= RT_STACK_LDS) e = deep[sp - RT_STACK_LDS];
+            if (top >= RT_STACK_LDS * 512u) e = deep[(top >> 9) - RT_STACK_LDS];
             if (__uint_as_float(e.y) <= limit) return e.x;
         }
         return REF_NONE;
@@ -517,7 +522,7 @@ struct Walker {
         r = ray;
         if (INST) { world_ray_park(ray); inst = REF_NONE; id_off = 0; }
         box_ray_init(br, r, sc.radius);
-        st.lane = threadIdx.x & 63u; st.deep = deep_stack; st.sp = 0;
+        st.deep = deep_stack; st.reset(threadIdx.x & 63u);
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
         self_ref = 0xF0000000u;             // a leaf of fifteen: no tree has one, so neither cur nor a slot ever equals it
