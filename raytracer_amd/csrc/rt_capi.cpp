@@ -68,6 +68,9 @@ struct rt_ctx {
     // free lanes a persistent wave lets pile up before it swaps rays: walks through instances pay more per swap
     // (100M-triangle frame at 32 / 40 / 48: 22.2 / 21.7 / 21.4 ms; one-level scenes are best at 32)
     int refill() const { return refill_env ? refill_env : (sc.inst ? RT_REFILL_MIN_INST : RT_REFILL_MIN); }
+    int refill_primary_env = 0;            // RT_REFILL_MIN_PRIMARY from the environment (experiments)
+    // closest-hit launches of a plain scene: camera rays are cheap to set up and their walks end together more often
+    int refill_primary() const { return refill_primary_env ? refill_primary_env : (refill_env ? refill_env : (sc.inst ? RT_REFILL_MIN_INST : RT_REFILL_MIN)); }   // 28-44 time the same: no value of its own
     bool entry_search = true;              // start a tile's walks below the root where its beam allows (rt_ctx_set_entry_search)
     bool brute_force = false;              // closest-hit entry points test every primitive against every ray (rt_ctx_set_brute_force)
     // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
@@ -406,6 +409,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
             if (const char* env = std::getenv("RT_WAVE_DIV")) { const int v = std::atoi(env); if (v >= 1 && v <= 1024) c->wave_div = static_cast<uint32_t>(v); }
             if (const char* env = std::getenv("RT_ENTRY_SEARCH")) c->entry_search = std::atoi(env) != 0;
             if (const char* env = std::getenv("RT_REFILL_MIN")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_env = v; }
+            if (const char* env = std::getenv("RT_REFILL_MIN_PRIMARY")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) c->refill_primary_env = v; }
         }
     }
     // this GPU's address of the library's fixed workspace, looked up once per device with the device current
@@ -805,7 +809,7 @@ int run_bounce_pipeline(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, ui
         if (fb.entry_p && level == 0) ctx->mark_end();
         ctx->mark_begin(0);
         RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting,
-                                 level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill()));
+                                 level == 0 ? hit_id_dev : nullptr, nullptr, &fb, ctx->d_ctr, q, ctx->refill_primary()));
         ctx->mark_end();
         for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
             const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
@@ -845,7 +849,7 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     if (fb.entry_p) ctx->mark_end();
     ctx->mark_begin(0);
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, hit_id_dev, nullptr,
-                             &fb, ctx->d_ctr, q, ctx->refill()));
+                             &fb, ctx->d_ctr, q, ctx->refill_primary()));
     ctx->mark_end();
     for (uint32_t l0 = 0; l0 < n_lights; l0 += batch) {
         const uint32_t nb = (n_lights - l0 < batch) ? n_lights - l0 : batch;
@@ -874,7 +878,7 @@ int run_shadow_mask(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     if (fb.entry_p) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, 0, ctx->counting, &fb, ctx->d_ctr));
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, n_waves), ctx->counting, nullptr, nullptr,
-                             &fb, ctx->d_ctr, q, ctx->refill()));
+                             &fb, ctx->d_ctr, q, ctx->refill_primary()));
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     if (fb.entry_s) RT_HIP(rt_launch_entry_search(ctx->stream, &ctx->sc, &dc, &pm, n_waves, 0, n_lights, ctx->counting, &fb, ctx->d_ctr));
     RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * n_lights), 0, n_lights,
@@ -921,7 +925,7 @@ int rt_trace_primary(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int32_t* h
     unsigned int* q = nullptr;
     if (int rc = next_queue(ctx, qb, &q)) return rc;
     RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, dist_dev, nullptr,
-                             ctx->d_ctr, q, ctx->refill()));
+                             ctx->d_ctr, q, ctx->refill_primary()));
     return RT_OK;
 }
 
@@ -1021,7 +1025,7 @@ int render_rect(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, int max_scatter
             unsigned int* q = nullptr;
             if (int rc = next_queue(ctx, qb, &q)) return rc;
             RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
-                                     ctx->d_ctr, q, ctx->refill()));
+                                     ctx->d_ctr, q, ctx->refill_primary()));
         }
         return RT_OK;
     }
@@ -1072,7 +1076,7 @@ int rt_render_rect_static(rt_ctx* ctx, const rt_camera* cam, rt_rect rect, uint8
             unsigned int* q = nullptr;
             if (int rc = next_queue(ctx, qb, &q)) return rc;
             RT_HIP(rt_launch_primary(ctx->stream, &ctx->sc, &dc, &pm, nw, wave_count(ctx, nw), ctx->counting, hit_id_dev, nullptr, nullptr,
-                                     ctx->d_ctr, q, ctx->refill()));
+                                     ctx->d_ctr, q, ctx->refill_primary()));
         }
         return RT_OK;
     }
