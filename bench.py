@@ -352,7 +352,8 @@ def main():
         for name in sorted((f for f in os.listdir(pdir) if f.endswith("_traffic.json")), reverse=True):
             tj = json.load(open(os.path.join(pdir, name)))
             # a measurement belongs to one set of kernels on one workload: the file must carry this build's source hash
-            if (world == 1 and args.max_scatters == 0 and tj["workload"]["n_side"] == args.n_side
+            if (world == 1 and tj["workload"]["max_scatters"] == args.max_scatters and tj["workload"]["n_side"] == args.n_side
+                    and bool(tj["workload"].get("instanced")) == args.instanced and bool(tj["workload"].get("device_build")) == args.device_build
                     and tj["workload"]["rays_per_frame"] == rays_per_frame and tj.get("res", "3840x2160") == "%dx%d" % (W, H)
                     and tj.get("algorithmic_bytes_per_launch") == k_bytes and tj.get("kernel_source_sha16") == kernel_source_sha16()):
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + name
@@ -383,7 +384,7 @@ def main():
                             % ("%dM" % round(args.n_side ** 2 / 1e6) if args.n_side >= 1000 else "%dk" % round(args.n_side ** 2 / 1e3), W, H, len(lights)),
                 "n_side": args.n_side, "n_prims": int(info.n_instanced_prims if args.instanced else info.n_prims), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.depth),
                 "wide_nodes": (2 * int(info.n_slots) if ctx.build_time_ms() > 0 else scene.n_wide()),
-                "max_scatters": args.max_scatters, "tile": args.tile if world > 1 else None,
+                "max_scatters": args.max_scatters, "instanced": args.instanced, "device_build": args.device_build, "tile": args.tile if world > 1 else None,
                 "partition": ("image tiles round-robin over %d ranks, scene replicated, %s to rank 0" % (world, gather_path)
                               + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")) if world > 1 else "single GPU",
                 "rays_per_frame": rays_per_frame, "primary_rays": total["primary_rays"], "primary_hits": total["primary_hits"],

@@ -29,7 +29,7 @@ def main(src, dst):
     KERNEL = max((k for k in fetch if k.startswith(SHADOW)), key=lambda k: fetch[k])
     out = {
         "kernel": KERNEL,
-        "workload": {k: bench["config"][k] for k in ("n_side", "n_prims", "rays_per_frame", "max_scatters")},
+        "workload": {k: bench["config"].get(k) for k in ("n_side", "n_prims", "rays_per_frame", "max_scatters", "instanced", "device_build")},
         "kernel_source_sha16": bench["config"].get("kernel_source_sha16"),
         "res": bench["metric"].rsplit(" ", 1)[-1],
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
