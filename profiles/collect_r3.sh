@@ -2,6 +2,7 @@
 # Measurement recipe behind profiles/r3 (and profiles/r3/hbm), run on the GPU box from the repository root:
 #   bash profiles/collect_r3.sh r3                       the headline workload (1M cells, 3840x2160, 4 lights)
 #   bash profiles/collect_r3.sh r3_hbm --n-side 4000     16M cells: nodes and records far beyond the 256 MiB Infinity Cache
+#   bash profiles/collect_r3.sh r3_inst --instanced --max-scatters 2     100 M instanced triangles, two mirror bounces
 # Kernel stats of the bench command (rocprofv3 --kernel-trace --stats), then one PMC pass per counter group, each in a run
 # of its own (FETCH_SIZE, WRITE_SIZE, cache hits / L1 requests, issue mix and lane utilisation, waits, the L1 request
 # path), then the HBM-side bytes per launch (make_traffic.py) and the bench line that reports them.
