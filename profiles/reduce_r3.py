@@ -42,12 +42,15 @@ def extra(out):
     """The bench lines and kernel stats of collect_r3_extra.sh."""
     raw = os.path.join(ROOT, "gpurun_out", "r3_extra")
     out = os.path.join(ROOT, out)
-    for tag, name in (("inst", "instanced"), ("devbuild", "device_build")):
+    for tag, name in (("devbuild", "device_build"),):
         src = os.path.join(raw, tag, tag + "_kernel_stats.csv")
         if os.path.exists(src):
             stats(src, os.path.join(out, "kernel_stats_%s.csv" % name))
-    for name in ("inst_bench.json", "devbuild_bench.json", "res8k_bench.json", "bounce2_bench.json", "config2.json"):
+    for name in ("devbuild_bench.json", "res8k_bench.json", "bounce2_bench.json", "config2.json", "tile_share_4k_8k.txt"):
         if os.path.exists(os.path.join(raw, name)):
+            if name.endswith(".txt"):
+                shutil.copy(os.path.join(raw, name), os.path.join(out, name))
+                continue
             lines = open(os.path.join(raw, name)).read().strip().splitlines()
             open(os.path.join(out, name), "w").write(lines[-1] + "\n")
 
