@@ -71,6 +71,9 @@ struct rt_ctx {
     int refill_primary_env = 0;            // RT_REFILL_MIN_PRIMARY from the environment (experiments)
     // closest-hit launches of a plain scene: camera rays are cheap to set up and their walks end together more often
     int refill_primary() const { return refill_primary_env ? refill_primary_env : (refill_env ? refill_env : (sc.inst ? RT_REFILL_MIN_INST : RT_REFILL_MIN)); }   // 28-44 time the same: no value of its own
+    // the resolve of a one-batch frame in two passes (mixed precision for every slot it decides, FP64 for the listed rest):
+    // pays when few slots need the second pass, i.e. when few materials have highlights too sharp for the first
+    bool two_pass_resolve = false;
     bool entry_search = true;              // start a tile's walks below the root where its beam allows (rt_ctx_set_entry_search)
     bool brute_force = false;              // closest-hit entry points test every primitive against every ray (rt_ctx_set_brute_force)
     // optional per-launch timing: (kind, start, stop) triples drawn from a pool of events
@@ -663,6 +666,18 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene* scene) {
         if (rc == RT_OK) rc = upload(scene->slot_prim, &ctx->d_slot_prim);
     }
     if (rc == RT_OK) rc = upload(scene->mats, &ctx->d_mats);
+    {
+        // materials whose Blinn-Phong exponent (2 / roughness^2 - 2, raytracer.cpp:247-249) is above 64: the mixed-precision
+        // light term is not used for them.  With the scene's highlights mostly sharp (a sixty-fourth of the materials or
+        // more) the single-pass resolve, which holds both forms, is the faster one (0.38 against 0.79 ms on the 4K frame
+        // with every roughness at 0.1).
+        size_t sharp = 0;
+        for (const rt_mat_rec& m : scene->mats) {
+            const float r = std::fmin(std::fmax(static_cast<float>(m.roughness), 0.001f), 1.0f);
+            sharp += (2.0f / (r * r) - 2.0f > 64.0f) ? 1u : 0u;
+        }
+        ctx->two_pass_resolve = sharp * 64u < scene->mats.size();
+    }
     if (rc == RT_OK) rc = upload(scene->lights, &ctx->d_lights);
     if (rc == RT_OK) rc = upload(scene->texels, &ctx->d_texels);
     if (rc == RT_OK) rc = upload(scene->tex_table, &ctx->d_tex_table);
@@ -716,6 +731,18 @@ int next_queue(rt_ctx* ctx, QueueBlock& qb, unsigned int** q) {
     }
     *q = qb.base + qb.used;
     qb.used += RT_QUEUE_PARTS;
+    return RT_OK;
+}
+
+// RT_RESOLVE_PARTS zeroed words out of the same block, for the counts of the two-pass resolve.
+int take_list_heads(rt_ctx* ctx, QueueBlock& qb, unsigned int** heads) {
+    static_assert(RT_RESOLVE_PARTS + 4u * RT_QUEUE_PARTS <= kQueueSlots, "a plain frame's launches and the list counts fit one block");
+    if (qb.used + RT_RESOLVE_PARTS > kQueueSlots) {
+        RT_HIP(hipMemsetAsync(qb.base, 0, kQueueSlots * sizeof(unsigned int), ctx->stream));
+        qb.used = 0;
+    }
+    *heads = qb.base + qb.used;
+    qb.used += RT_RESOLVE_PARTS;
     return RT_OK;
 }
 
@@ -861,8 +888,11 @@ int run_pipeline_on(rt_ctx* ctx, const DevCamera& dc, const PixelMap& pm, uint32
         RT_HIP(rt_launch_shadow(ctx->stream, &ctx->sc, &dc, &pm, n_waves, wave_count(ctx, static_cast<uint64_t>(n_waves) * nb), l0, nb,
                                 ctx->counting, &fb, ctx->d_ctr, q, ctx->refill()));
         ctx->mark_end();
+        // all lights in one batch: the resolve runs in two passes and counts the slots of the second in zeroed words
+        unsigned int* list_head = nullptr;
+        if (l0 == 0 && nb >= n_lights && ctx->two_pass_resolve) { if (int rc = take_list_heads(ctx, qb, &list_head)) return rc; }
         ctx->mark_begin(2);
-        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &dc, &pm, &fb, l0, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev));
+        RT_HIP(rt_launch_resolve(ctx->stream, &ctx->sc, &dc, &pm, &fb, l0, nb, l0 == 0, l0 + nb >= n_lights, rgb_dev, list_head));
         ctx->mark_end();
     }
     return RT_OK;

@@ -15,6 +15,9 @@
 #define RT_RAYS_MIN_WAVES 4        // waves per SIMD the persistent kernel is compiled for (caps VGPRs at 128)
 #endif
 #define RT_QUEUE_PARTS 8u          // work-queue heads per launch: one per XCD
+#ifndef RT_RESOLVE_PARTS
+#define RT_RESOLVE_PARTS 256u      // parts (each with its own count) of the list between the two passes of the resolve
+#endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 256u              // consecutive rays a persistent wave takes per queue access (4 tiles)
 #endif
@@ -134,7 +137,7 @@ hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const DevCamera*
                             uint32_t n_tiles, uint32_t n_waves, uint32_t light0, uint32_t n_batch, int counting,
                             const FrameBufs* fb, rt_counters* ctr, unsigned int* queue, int refill_min);
 hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const FrameBufs* fb, uint32_t light0, uint32_t n_batch,
-                             int first, int last, uint8_t* rgb);
+                             int first, int last, uint8_t* rgb, unsigned int* list_heads);
 hipError_t rt_launch_verdict_mask(hipStream_t st, const PixelMap* pm, const FrameBufs* fb, uint32_t n_batch, uint8_t* mask);
 hipError_t rt_launch_trace_rays(hipStream_t st, const DevScene* sc, const double* rays, uint64_t n, int counting, int shade_it,
                                 int32_t* ids, double* dist, uint8_t* rgb, double* records, rt_counters* ctr);

@@ -753,11 +753,18 @@ DEV void normalize3f(float x, float y, float z, float& ox, float& oy, float& oz)
 }
 // bound: grows by an upper bound of this term's absolute error (attenuation times the relative error of diffuse + specular:
 // a few roundings of 2^-24 each, and e times as much again through the power).
+// mixed_phong_exp: the exponent as this form computes it; above RT_MIXED_MAX_EXP the FP64 form is taken (FALLBACK), or
+// the caller has made sure beforehand that the material does not get here (the first pass of the two-pass resolve).
+constexpr float RT_MIXED_MAX_EXP = 64.0f;
+DEV float mixed_phong_exp(const rt_mat_rec& m) {
+    const float roughness = fminf(fmaxf(static_cast<float>(m.roughness), 0.001f), 1.0f);
+    return fmaxf(2.0f / (roughness * roughness) - 2.0f, 2.0f);
+}
+template <bool FALLBACK = true>
 DEV double light_value_mixed(const rt_light& L, const rt_mat_rec& m, double px, double py, double pz,
                              double nx, double ny, double nz, double view_ox, double view_oy, double view_oz, float& bound) {
-    const float roughness = fminf(fmaxf(static_cast<float>(m.roughness), 0.001f), 1.0f);
-    const float phong_exp = fmaxf(2.0f / (roughness * roughness) - 2.0f, 2.0f);
-    if (phong_exp > 64.0f) {
+    const float phong_exp = mixed_phong_exp(m);
+    if (FALLBACK && phong_exp > RT_MIXED_MAX_EXP) {
         double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);
         return light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, view_ox, view_oy, view_oz);        // exact: adds nothing to the bound
     }
@@ -1531,7 +1538,7 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
 // The terms of the lights of one batch that reach surface point i, added in light order (the reference's accumulation
 // order, raytracer.cpp:210-260) to `lighting`.  view = origin of the ray that found the surface (raytracer.cpp:185-186).
 // MIXED: the terms in mixed precision (light_value_mixed), *bound = an upper bound of the sum's absolute error.
-template <bool MIXED = false>
+template <int MIXED = 0>          // 0: FP64; 1: mixed precision, FP64 for sharp highlights; 2: mixed precision only
 DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, const PixelMap& pm, size_t i, uint32_t light0, uint32_t n_batch, const rt_mat_rec& m,
                           double vox, double voy, double voz, double lighting, float* bound = nullptr) {
     const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
@@ -1542,13 +1549,28 @@ DEV double add_lit_lights(const DevScene& sc, const FrameBufs& fb, const PixelMa
     for (uint32_t j = 0; j < n_batch; ++j) {
         if (!lit[64u * j]) continue;
         const rt_light L = sc.lights[light0 + j];
-        if (MIXED) { lighting += light_value_mixed(L, m, px, py, pz, nx, ny, nz, vox, voy, voz, *bound); continue; }
+        if (MIXED) { lighting += light_value_mixed<MIXED == 1>(L, m, px, py, pz, nx, ny, nz, vox, voy, voz, *bound); continue; }
         double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
         lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, vox, voy, voz);
     }
     return lighting;
 }
 
+// Can a light sum that is off by up to `bound` round a channel of the colour differently?
+DEV bool mixed_sum_undecided(const rt_mat_rec& m, uint32_t albedo, double lighting, float bound) {
+    const double metallic = clampd(m.metallic, 0.0, 1.0);
+    double intensity = (1.0 - metallic) * 0.05 + lighting;
+    intensity = intensity < 0.0 ? 0.0 : (intensity > 1.0 ? 1.0 : intensity);
+    const double tol = 1e-4 + 255.0 * static_cast<double>(bound);
+    bool undecided = !(tol < 0.25);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double c = intensity * static_cast<double>((albedo >> (8 * k)) & 255u);
+        const double f = c - __builtin_floor(c);
+        undecided = undecided || __builtin_fabs(f - 0.5) < tol;
+    }
+    return undecided;
+}
 // The light sum of slot i after this batch, for the resolve kernels.  When the batch holds all the lights the sum is made
 // in mixed precision first, with a bound on its error: the colour is round(intensity * albedo) per channel, so it can
 // only differ from the FP64 result where a channel's product lies within that error of a half; such slots (with the
@@ -1561,21 +1583,11 @@ DEV double resolve_lighting(const DevScene& sc, const FrameBufs& fb, const Pixel
 #if RT_MIXED_RESOLVE
     if (first && last) {
         float bound = 0.0f;
-        lighting = add_lit_lights<true>(sc, fb, pm, i, light0, n_batch, m, vox, voy, voz, 0.0, &bound);
-        const double metallic = clampd(m.metallic, 0.0, 1.0);
-        double intensity = (1.0 - metallic) * 0.05 + lighting;
-        intensity = intensity < 0.0 ? 0.0 : (intensity > 1.0 ? 1.0 : intensity);
-        const double tol = 1e-4 + 255.0 * static_cast<double>(bound);
-        exact = !(tol < 0.25);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double c = intensity * static_cast<double>((albedo >> (8 * k)) & 255u);
-            const double f = c - __builtin_floor(c);
-            exact = exact || __builtin_fabs(f - 0.5) < tol;
-        }
+        lighting = add_lit_lights<1>(sc, fb, pm, i, light0, n_batch, m, vox, voy, voz, 0.0, &bound);
+        exact = mixed_sum_undecided(m, albedo, lighting, bound);
     }
 #endif
-    if (exact) lighting = add_lit_lights<false>(sc, fb, pm, i, light0, n_batch, m, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
+    if (exact) lighting = add_lit_lights<0>(sc, fb, pm, i, light0, n_batch, m, vox, voy, voz, first ? 0.0 : fb.lighting[i]);
     return lighting;
 }
 
@@ -1596,6 +1608,110 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, DevCamera cam, Pix
     if (!last) { fb.lighting[i] = lighting; return; }
     const uint32_t c = finish_shade(m, albedo, lighting);
     rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
+}
+
+// The same for a frame whose lights fit one batch, in two passes.  The FP64 form of the light terms (its `pow` above all)
+// costs the kernel that holds it twice the registers of the mixed-precision form, and only one slot in a few hundred
+// needs it.  So the first pass knows the mixed form only: it colours every slot whose sum is decided (resolve_lighting's
+// test) and appends the others - and every slot of a material with a highlight too sharp for the mixed form - to a list;
+// the second pass colours the listed slots in FP64.  The colours are the ones k_resolve writes.
+// list: fb.lighting's memory (unused when there is one batch), as 32-bit slot numbers; *head: their count, zero before.
+// lights: sc.lights + light0 once more, as a parameter of its own that promises not to alias anything written here - the
+// batch's lights are then scalar operands wherever the loop stands (read through `sc` they are fetched per lane, one
+// more trip to memory per light, because the sky colour has been stored by then).
+__global__ void __launch_bounds__(256) k_resolve_decided(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, const rt_light* __restrict__ lights,
+                                                         uint32_t n_batch, uint8_t* __restrict__ rgb, unsigned int* __restrict__ heads, uint32_t part_cap) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool valid = i < fb.n;
+    const size_t ii = valid ? i : 0;
+    // Whatever depends on the slot number alone is asked for in one go - the id, the surface point and normal, the
+    // verdict bytes of all the batch's lights (ray (tile, light j, lane) of the shadow launch wrote byte
+    // (tile * n_batch + j) * 64 + lane) - so that a slot costs two trips to memory (these, then its material), not one
+    // per verdict byte.
+    int32_t id = fb.id[ii];
+    const double px = fb.px[ii], py = fb.py[ii], pz = fb.pz[ii], nx = fb.nx[ii], ny = fb.ny[ii], nz = fb.nz[ii];
+    uint32_t tile_w, ray_lane;
+    slot_to_ray(pm, ii, tile_w, ray_lane);
+    const uint8_t* lit = fb.lit + (static_cast<size_t>(tile_w) * n_batch) * 64u + ray_lane;
+    uint32_t verdict[RT_LIGHT_BATCH];                       // places beyond the batch repeat its last byte and are not looked at
+#pragma unroll
+    for (uint32_t j = 0; j < RT_LIGHT_BATCH; ++j) verdict[j] = lit[64u * (j < n_batch ? j : n_batch - 1u)];
+    uint32_t tex_albedo = fb.albedo ? fb.albedo[ii] : 0u;
+    asm volatile("" : "+v"(id), "+v"(tex_albedo));                  // the loads stay up here
+    bool defer = false;
+    if (valid) {
+        if (id < 0) { rgb[i*3] = sc.gamma[0]; rgb[i*3 + 1] = sc.gamma[0]; rgb[i*3 + 2] = sc.gamma[0]; }
+        else {
+            const rt_mat_rec m = sc.mats[id];
+            const uint32_t albedo = fb.albedo ? tex_albedo : solid_albedo(m);
+            defer = mixed_phong_exp(m) > RT_MIXED_MAX_EXP;
+            if (!defer) {
+                float bound = 0.0f;
+                double lighting = 0.0;
+                // every lane goes through every light of the batch and keeps the terms of those that reach it (in light
+                // order, as the reference adds them): a branch per lane would not save the wave anything, and the light
+                // stays a scalar operand
+#pragma unroll
+                for (uint32_t j = 0; j < RT_LIGHT_BATCH; ++j) {
+                    if (j >= n_batch) break;
+                    const rt_light L = lights[j];
+                    float b = 0.0f;
+                    const double term = light_value_mixed<false>(L, m, px, py, pz, nx, ny, nz, cam.pos[0], cam.pos[1], cam.pos[2], b);
+                    lighting = verdict[j] ? lighting + term : lighting;
+                    bound = verdict[j] ? bound + b : bound;
+                }
+                defer = mixed_sum_undecided(m, albedo, lighting, bound);
+                if (!defer) {
+                    const uint32_t c = finish_shade(m, albedo, lighting);
+                    rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
+                }
+            }
+        }
+    }
+    // one addition to a count per wave.  The list is kept in RT_RESOLVE_PARTS parts, each with a count of its own (blocks
+    // take them in turn, so part_cap = 256 * the blocks of a part bounds what a part can hold): additions to one word from
+    // all over the chip are carried out one after the other on the memory side, and twenty thousand of them on one
+    // word - or on eight - cost three times what the second pass saves.
+    const unsigned long long dm = __ballot(defer);
+    if (dm) {
+        const uint32_t lane = threadIdx.x & 63u, part = blockIdx.x % RT_RESOLVE_PARTS;
+        unsigned int base = 0;
+        if (lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(dm)) - 1)) base = atomicAdd(heads + part, static_cast<unsigned int>(__popcll(dm)));
+        base = __shfl(base, __ffsll(static_cast<long long>(dm)) - 1, 64);
+        if (defer) reinterpret_cast<uint32_t*>(fb.lighting)[static_cast<size_t>(part) * part_cap + base + static_cast<uint32_t>(__popcll(dm & ((1ull << lane) - 1ull)))] = static_cast<uint32_t>(i);
+    }
+}
+// blockIdx.y: the part of the list; one wave per block and a few blocks per part, all resident at once: a part holds
+// a hundred slots or so, unless the scene's highlights are sharp - then it holds all its slots, and the waves loop.
+__global__ void __launch_bounds__(64) k_resolve_listed(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, const rt_light* __restrict__ lights,
+                                                       uint32_t n_batch, uint8_t* __restrict__ rgb, const unsigned int* __restrict__ heads, uint32_t part_cap) {
+    const uint32_t n_listed = heads[blockIdx.y];
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(fb.lighting) + static_cast<size_t>(blockIdx.y) * part_cap;
+    for (uint32_t j = blockIdx.x * 64u + threadIdx.x; j < n_listed; j += gridDim.x * 64u) {
+        const size_t i = list[j];
+        // as in the first pass: what depends on the slot number alone in one go, then the material
+        int32_t id = fb.id[i];
+        const double px = fb.px[i], py = fb.py[i], pz = fb.pz[i], nx = fb.nx[i], ny = fb.ny[i], nz = fb.nz[i];
+        uint32_t tile_w, ray_lane;
+        slot_to_ray(pm, i, tile_w, ray_lane);
+        const uint8_t* lit = fb.lit + (static_cast<size_t>(tile_w) * n_batch) * 64u + ray_lane;
+        uint32_t verdict[RT_LIGHT_BATCH];
+#pragma unroll
+        for (uint32_t k = 0; k < RT_LIGHT_BATCH; ++k) verdict[k] = lit[64u * (k < n_batch ? k : n_batch - 1u)];
+        uint32_t tex_albedo = fb.albedo ? fb.albedo[i] : 0u;
+        asm volatile("" : "+v"(id), "+v"(tex_albedo));
+        const rt_mat_rec m = sc.mats[id];
+        const uint32_t albedo = fb.albedo ? tex_albedo : solid_albedo(m);
+        double lighting = 0.0;
+        for (uint32_t k = 0; k < n_batch; ++k) {
+            if (!verdict[k < RT_LIGHT_BATCH ? k : 0]) continue;
+            const rt_light L = lights[k];
+            double dx, dy, dz; normalize3(L.pos[0] - px, L.pos[1] - py, L.pos[2] - pz, dx, dy, dz);   // the shadow ray's direction
+            lighting += light_value(L, m, px, py, pz, nx, ny, nz, dx, dy, dz, cam.pos[0], cam.pos[1], cam.pos[2]);
+        }
+        const uint32_t c = finish_shade(m, albedo, lighting);
+        rgb[i*3] = sc.gamma[c & 255u]; rgb[i*3 + 1] = sc.gamma[(c >> 8) & 255u]; rgb[i*3 + 2] = sc.gamma[(c >> 16) & 255u];
+    }
 }
 
 // One byte per output slot: bit j set = light j of the batch reaches the slot's surface point; 0 where nothing was hit.
@@ -1977,10 +2093,24 @@ extern "C" hipError_t rt_launch_shadow(hipStream_t st, const DevScene* sc, const
     return hipGetLastError();
 }
 
+// list_heads: RT_RESOLVE_PARTS zeroed 32-bit words for the two-pass form (taken when the batch holds all the lights), or null.
 extern "C" hipError_t rt_launch_resolve(hipStream_t st, const DevScene* sc, const DevCamera* cam, const PixelMap* pm, const FrameBufs* fb, uint32_t light0,
-                                        uint32_t n_batch, int first, int last, uint8_t* rgb) {
+                                        uint32_t n_batch, int first, int last, uint8_t* rgb, unsigned int* list_heads) {
     const uint32_t nb = static_cast<uint32_t>((fb->n + 255) / 256);
-    if (nb) hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *pm, *fb, light0, n_batch, first, last, rgb);
+    if (nb == 0) return hipSuccess;
+#if RT_MIXED_RESOLVE
+    // the list lives in fb->lighting (8 n bytes, unused when there is one batch): RT_RESOLVE_PARTS parts of part_cap slot numbers
+    const uint32_t per_part = (nb + RT_RESOLVE_PARTS - 1u) / RT_RESOLVE_PARTS;
+    const uint64_t part_cap = 256ull * per_part;
+    if (first && last && list_heads && 4ull * RT_RESOLVE_PARTS * part_cap <= 8ull * fb->n && fb->n < (1ull << 32)) {
+        hipLaunchKernelGGL(k_resolve_decided, dim3(nb), dim3(256), 0, st, *sc, *cam, *pm, *fb, sc->lights + light0, n_batch, rgb, list_heads,
+                           static_cast<uint32_t>(part_cap));
+        hipLaunchKernelGGL(k_resolve_listed, dim3(per_part < 2u ? 4u * per_part : 8u, RT_RESOLVE_PARTS), dim3(64), 0, st, *sc, *cam, *pm, *fb, sc->lights + light0, n_batch, rgb,
+                           list_heads, static_cast<uint32_t>(part_cap));
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(k_resolve, dim3(nb), dim3(256), 0, st, *sc, *cam, *pm, *fb, light0, n_batch, first, last, rgb);
     return hipGetLastError();
 }
 
