@@ -732,7 +732,10 @@ DEV double light_value(const rt_light& L, const rt_mat_rec& m, double px, double
     double hx, hy, hz; normalize3(dx + vx, dy + vy, dz + vz, hx, hy, hz);
     const double ndh = nx*hx + ny*hy + nz*hz;
     const double n_dot_h = (0.0 < ndh) ? ndh : 0.0;
-    const double specular = (0.5 * 1.25) * pow(n_dot_h, phong_exp);
+    // x^e for a sharp highlight is zero nearly everywhere: ln x <= x - 1, so e (x - 1) log2(e) < -1100 puts x^e below
+    // 2^-1100, which is 0 in FP64 however it is rounded - the value pow returns, without its three hundred instructions
+    // (a mirror's exponent is two million: only normals within a fiftieth of a degree of the half vector get past this)
+    const double specular = (phong_exp * (n_dot_h - 1.0) * 1.4426950408889634 < -1100.0) ? 0.0 : (0.5 * 1.25) * pow(n_dot_h, phong_exp);
     const double attenuation = L.intensity / dist2;
     return attenuation * (diffuse + specular);
 }
