@@ -1884,10 +1884,13 @@ __global__ void __launch_bounds__(64) k_shade_hits(DevScene sc, const double* __
     add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, F_SHADOW, sctr.shadow_rays);
 }
 
+#ifndef RT_BOUNCE_RESOLVE_WAVES
+#define RT_BOUNCE_RESOLVE_WAVES 4      // waves per SIMD the kernel below is compiled for: it streams 250 bytes per slot, and three waves are too few for that
+#endif
 // Mirror bounces (trace_ray_recursive, raytracer.cpp:281-371) as a level-by-level pipeline: each level is traced and
 // shadow-tested by the same ray kernels as a plain frame; this kernel closes a level - local colour, Fresnel weight,
 // tint, and the ray of the next level - and k_bounce_fold blends the levels back up once the chain has ended.
-__global__ void __launch_bounds__(256) k_bounce_resolve(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, LevelBufs lv, uint32_t light0, uint32_t n_batch, int first, int last,
+__global__ void __launch_bounds__(256, RT_BOUNCE_RESOLVE_WAVES) k_bounce_resolve(DevScene sc, DevCamera cam, PixelMap pm, FrameBufs fb, LevelBufs lv, uint32_t light0, uint32_t n_batch, int first, int last,
                                                         int max_scatters, double min_scatter_intensity) {
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= fb.n) return;
