@@ -28,7 +28,12 @@
 #define DEV __device__ __forceinline__
 #ifndef RT_ENTRY_ITERS_PRIMARY       // refinement steps of a tile's entry search at most: later steps cost the search more than
 #define RT_ENTRY_ITERS_PRIMARY 24    // they save the walks (frame time at 8 / 10 / 16 / 24 / 96 steps for both kinds of beam:
-#define RT_ENTRY_ITERS_SHADOW 16     // 6.36 / 5.97 / 5.81 / 5.82 / 5.93 ms on the 1.3 M-primitive 4K frame)
+#endif                               // 6.36 / 5.97 / 5.81 / 5.82 / 5.93 ms on the 1.3 M-primitive 4K frame)
+#ifndef RT_ENTRY_ITERS_SHADOW
+#define RT_ENTRY_ITERS_SHADOW 16
+#endif
+#ifndef RT_ENTRY_QUAD_MAX_BEAMS
+#define RT_ENTRY_QUAD_MAX_BEAMS 600000u   // entry searches of up to this many beams run with four lanes per beam (k_entry_quad)
 #endif
 #ifndef RT_INNER_EXIT_REL
 #define RT_INNER_EXIT_REL 4          // 0: lanes wait until every ray of the wave has left the inner nodes
@@ -1080,6 +1085,16 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     const uint32_t p0 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * q_part / RT_QUEUE_PARTS);
                     const uint32_t p1 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * (q_part + 1) / RT_QUEUE_PARTS);
                     unsigned int c = 0;
+                    // Another XCD's run, in a launch with a chunk or two per wave (a rank's share of a tiled frame): nearly every
+                    // wave comes by every head once, and most find the run used up.  A head that has passed its run's length
+                    // stays past it, so the wave looks before it adds: a look costs the others nothing, an addition queues
+                    // up behind theirs (closest-hit launch of an eighth of the 4K frame 0.32 -> 0.30 ms).  In a large launch
+                    // most visits to another run find work, and the look would be one more trip per chunk (3.44 -> 3.65 ms).
+                    if (q_tried > 0 && n_chunks <= 2u * gridDim.x) {
+                        if (lane == 0) c = __hip_atomic_load(queue + q_part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        c = __builtin_amdgcn_readfirstlane(c);
+                        if (c >= p1 - p0) { q_part = (q_part + 1) % RT_QUEUE_PARTS; ++q_tried; continue; }
+                    }
                     if (lane == 0) c = atomicAdd(queue + q_part, 1u);
                     c = __builtin_amdgcn_readfirstlane(c);
                     if (c < p1 - p0) {
@@ -1534,6 +1549,123 @@ __global__ void __launch_bounds__(256) k_entry(DevScene sc, DevCamera cam, Pixel
         out[4] = make_float4(bhi[0][1], bhi[1][1], bhi[2][1], bhi[3][1]);
         out[5] = make_float4(bhi[0][2], bhi[1][2], bhi[2][2], bhi[3][2]);
         out[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    }
+    if (counting) add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, shadow ? F_VN_S : F_VN_P, vn);
+}
+
+// The same search with four lanes per beam, one per place of the set and per child of the node being opened: the four
+// box tests of a step run side by side, and there are four times as many waves to overlap the steps' fetches.  The lanes
+// of a beam are an aligned quad, so what one needs of another comes by quad broadcasts (DPP) or one lane-indexed read;
+// every decision - which subtree to open, whether its children fit, which place a child takes - is the one the
+// one-lane search takes, so the entry nodes are the same bit for bit.
+template <int K> DEV uint32_t quad_lane(uint32_t v) {           // the value lane K of this lane's quad holds
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), K * 0x55, 0xF, 0xF, true));
+}
+template <int K> DEV float quad_lane(float v) { return __uint_as_float(quad_lane<K>(__float_as_uint(v))); }
+DEV uint32_t quad_bits(bool p) {                                // bit k = p in lane k of this lane's quad
+    return static_cast<uint32_t>(__ballot(p) >> (threadIdx.x & 60u)) & 15u;
+}
+template <bool SHADOW>
+__global__ void __launch_bounds__(256) k_entry_quad(DevScene sc, DevCamera cam, PixelMap pm, uint32_t n_tiles, uint32_t light0, uint32_t n_batch,
+                                                    int counting, FrameBufs fb, rt_counters* ctr) {
+    const uint32_t b = (blockIdx.x * 256u + threadIdx.x) >> 2, q = threadIdx.x & 3u;
+    constexpr bool shadow = SHADOW;
+    const uint32_t n_beams = shadow ? n_tiles * n_batch : n_tiles;
+    uint32_t vn = 0;
+    if (b < n_beams) {
+        const uint32_t tile = shadow ? b / n_batch : b;
+        double o_lo[3], o_hi[3], d_lo[3], d_hi[3], L[3];
+        bool any = true;
+        double pad = 1e-7 * static_cast<double>(sc.radius);
+        if (shadow) {
+            const float* t = fb.tile_box + static_cast<size_t>(tile) * 8u;
+            for (int k = 0; k < 3; ++k) { o_lo[k] = t[k]; o_hi[k] = t[3 + k]; }
+            any = o_lo[0] <= o_hi[0];
+            const rt_light Lt = sc.lights[light0 + b % n_batch];
+            for (int k = 0; k < 3; ++k) { L[k] = Lt.pos[k]; d_lo[k] = 0.0; d_hi[k] = 0.0; }
+            pad += 1.001e-4;
+        } else {
+            const Pixel p = map_pixel(pm, tile, 0u);
+            any = p.valid;
+            for (int k = 0; k < 3; ++k) { o_lo[k] = cam.pos[k]; o_hi[k] = cam.pos[k]; L[k] = 0.0; d_lo[k] = __builtin_inf(); d_hi[k] = -__builtin_inf(); }
+            for (int c = 0; c < 4 && any; ++c) {
+                const double px = static_cast<double>(p.x + ((c & 1) ? 8 : 0)), py = static_cast<double>(p.y + ((c & 2) ? 8 : 0));
+                const double xs = cam.eff_w * (px / cam.width - 0.5), ys = cam.eff_h * (0.5 - py / cam.height), zs = cam.focal;
+                const double w[3] = { cam.rot[0]*xs + cam.rot[1]*ys + cam.rot[2]*zs, cam.rot[3]*xs + cam.rot[4]*ys + cam.rot[5]*zs,
+                                      cam.rot[6]*xs + cam.rot[7]*ys + cam.rot[8]*zs };
+                for (int k = 0; k < 3; ++k) { d_lo[k] = fmin(d_lo[k], w[k]); d_hi[k] = fmax(d_hi[k], w[k]); }
+            }
+            double wmax = 0.0;
+            for (int k = 0; k < 3; ++k) wmax = fmax(wmax, fmax(fabs(d_lo[k]), fabs(d_hi[k])));
+            for (int k = 0; k < 3; ++k) { d_lo[k] -= 1e-9 * wmax; d_hi[k] += 1e-9 * wmax; }
+        }
+        ShadowBeam sb;
+        PrimaryBeam pb;
+        if (shadow) shadow_beam_init(sb, o_lo, o_hi, L); else primary_beam_init(pb, o_lo, d_lo, d_hi);
+        auto touches = [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
+            const double lo[3] = { lx - pad, ly - pad, lz - pad }, hi[3] = { hx + pad, hy + pad, hz + pad };
+            return shadow ? beam_touches_shadow(sb, lo, hi) : beam_touches_primary(pb, lo, hi);
+        };
+        // this lane's place of the set (an empty place keeps an inverted box: the walks rely on it)
+        uint32_t ref = REF_NONE;
+        float blo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, bhi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+        bool closed = false;
+        if (any) {
+            if (q == 0) vn += 1;
+            if (q == 0 && touches(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2], sc.root_hi[0], sc.root_hi[1], sc.root_hi[2])) {
+                ref = sc.root_ref;
+                for (int k = 0; k < 3; ++k) { blo[k] = sc.root_lo[k]; bhi[k] = sc.root_hi[k]; }
+            }
+        }
+        for (int iter = 0; iter < (SHADOW ? RT_ENTRY_ITERS_SHADOW : RT_ENTRY_ITERS_PRIMARY); ++iter) {
+            // the widest subtree that can still be refined goes first (the lowest place among equals)
+            const uint32_t count = static_cast<uint32_t>(__popc(quad_bits(ref != REF_NONE)));
+            float size = -1.0f;
+            if (ref != REF_NONE && ref_internal(ref) && !closed) {
+                const float ex = bhi[0] - blo[0], ey = bhi[1] - blo[1], ez = bhi[2] - blo[2];
+                size = ex * ey + ey * ez + ez * ex;
+            }
+            const float s0 = quad_lane<0>(size), s1 = quad_lane<1>(size), s2 = quad_lane<2>(size), s3 = quad_lane<3>(size);
+            int pick = -1; float widest = -1.0f;
+            if (s0 > widest) { widest = s0; pick = 0; }
+            if (s1 > widest) { widest = s1; pick = 1; }
+            if (s2 > widest) { widest = s2; pick = 2; }
+            if (s3 > widest) { widest = s3; pick = 3; }
+            if (pick < 0) break;
+            const uint32_t r0 = quad_lane<0>(ref), r1 = quad_lane<1>(ref), r2 = quad_lane<2>(ref), r3 = quad_lane<3>(ref);
+            const uint32_t node = pick == 0 ? r0 : (pick == 1 ? r1 : (pick == 2 ? r2 : r3));
+            // child q of that node
+            const float* n4 = reinterpret_cast<const float*>(sc.nodes4 + 8u * static_cast<size_t>(node)) + q;
+            const float cl[3] = { n4[0], n4[4], n4[8] }, ch[3] = { n4[12], n4[16], n4[20] };
+            const uint32_t cr = __float_as_uint(n4[24]);
+            if (q == 0) vn += 4;
+            const bool h = cr != REF_NONE && touches(cl[0], cl[1], cl[2], ch[0], ch[1], ch[2]);
+            const uint32_t hits = quad_bits(h), nh = static_cast<uint32_t>(__popc(hits));
+            if (count - 1u + nh > 4u) { if (static_cast<int>(q) == pick) closed = true; continue; }
+            if (static_cast<int>(q) == pick) {
+                ref = REF_NONE;
+                for (int a = 0; a < 3; ++a) { blo[a] = __builtin_inff(); bhi[a] = -__builtin_inff(); }
+            }
+            if (nh == 0) closed = false;                          // a place came free: the others get another chance
+            // the touched children, in order, take the free places, in order
+            const uint32_t free_places = quad_bits(ref == REF_NONE);
+            const uint32_t j = static_cast<uint32_t>(__popc(free_places & ((1u << q) - 1u)));       // this place is the j-th free one
+            const bool take = ref == REF_NONE && j < nh;
+            // the j-th touched child: drop the j lowest set bits of `hits`, take the lowest that is left
+            uint32_t rest = hits;
+            for (uint32_t d = 0; d < 3u; ++d) if (d < j) rest &= rest - 1u;
+            const uint32_t src = (threadIdx.x & 60u) + (rest ? static_cast<uint32_t>(__ffs(static_cast<int>(rest)) - 1) : 0u);
+            const uint32_t t_ref = __shfl(cr, static_cast<int>(src), 64);
+            const float t_l0 = __shfl(cl[0], static_cast<int>(src), 64), t_l1 = __shfl(cl[1], static_cast<int>(src), 64), t_l2 = __shfl(cl[2], static_cast<int>(src), 64);
+            const float t_h0 = __shfl(ch[0], static_cast<int>(src), 64), t_h1 = __shfl(ch[1], static_cast<int>(src), 64), t_h2 = __shfl(ch[2], static_cast<int>(src), 64);
+            if (take) {
+                ref = t_ref; closed = false;
+                blo[0] = t_l0; blo[1] = t_l1; blo[2] = t_l2; bhi[0] = t_h0; bhi[1] = t_h1; bhi[2] = t_h2;
+            }
+        }
+        float* out = reinterpret_cast<float*>((shadow ? fb.entry_s : fb.entry_p) + 8u * static_cast<size_t>(b)) + q;   // b = tile, or tile * n_batch + light
+        out[0] = blo[0]; out[4] = blo[1]; out[8] = blo[2]; out[12] = bhi[0]; out[16] = bhi[1]; out[20] = bhi[2];
+        out[24] = __uint_as_float(ref);
     }
     if (counting) add_counter(ctr, blockIdx.x % RT_CTR_SHARDS, shadow ? F_VN_S : F_VN_P, vn);
 }
@@ -2078,9 +2210,19 @@ extern "C" hipError_t rt_launch_entry_search(hipStream_t st, const DevScene* sc,
                                              uint32_t light0, uint32_t n_batch, int counting, const FrameBufs* fb, rt_counters* ctr) {
     const uint64_t n_beams = static_cast<uint64_t>(n_tiles) * (n_batch ? n_batch : 1u);
     if (!sc->nodes4 || !fb || !fb->entry_p || n_beams == 0) return hipSuccess;
-    const dim3 grid(static_cast<uint32_t>((n_beams + 255u) / 256u));
-    if (n_batch) hipLaunchKernelGGL(k_entry<true>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
-    else         hipLaunchKernelGGL(k_entry<false>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
+    // One lane per beam is paced by its own instruction stream once there are eight or more waves per SIMD; four lanes
+    // per beam run more instructions in total but a quarter as many per wave, which is what counts while the launch is
+    // too small to fill the SIMDs: a rank's share of a tiled frame, or any frame up to 4K (searches of the 4K frame 0.217
+    // against 0.212 ms, of an eighth of it 0.110 against 0.060; of the 8K frame 0.64 against 0.72).
+    if (n_beams > RT_ENTRY_QUAD_MAX_BEAMS) {
+        const dim3 grid(static_cast<uint32_t>((n_beams + 255u) / 256u));
+        if (n_batch) hipLaunchKernelGGL(k_entry<true>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
+        else         hipLaunchKernelGGL(k_entry<false>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
+        return hipGetLastError();
+    }
+    const dim3 grid(static_cast<uint32_t>((n_beams + 63u) / 64u));          // four lanes per beam
+    if (n_batch) hipLaunchKernelGGL(k_entry_quad<true>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
+    else         hipLaunchKernelGGL(k_entry_quad<false>, grid, dim3(256), 0, st, *sc, *cam, *pm, n_tiles, light0, n_batch, counting, *fb, ctr);
     return hipGetLastError();
 }
 
