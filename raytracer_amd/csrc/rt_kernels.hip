@@ -1085,16 +1085,6 @@ __global__ void __launch_bounds__(64, RT_RAYS_MIN_WAVES) k_rays(DevScene sc, Dev
                     const uint32_t p0 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * q_part / RT_QUEUE_PARTS);
                     const uint32_t p1 = static_cast<uint32_t>(static_cast<unsigned long long>(n_chunks) * (q_part + 1) / RT_QUEUE_PARTS);
                     unsigned int c = 0;
-                    // Another XCD's run, in a launch with a chunk or two per wave (a rank's share of a tiled frame): nearly every
-                    // wave comes by every head once, and most find the run used up.  A head that has passed its run's length
-                    // stays past it, so the wave looks before it adds: a look costs the others nothing, an addition queues
-                    // up behind theirs (closest-hit launch of an eighth of the 4K frame 0.32 -> 0.30 ms).  In a large launch
-                    // most visits to another run find work, and the look would be one more trip per chunk (3.44 -> 3.65 ms).
-                    if (q_tried > 0 && n_chunks <= 2u * gridDim.x) {
-                        if (lane == 0) c = __hip_atomic_load(queue + q_part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        c = __builtin_amdgcn_readfirstlane(c);
-                        if (c >= p1 - p0) { q_part = (q_part + 1) % RT_QUEUE_PARTS; ++q_tried; continue; }
-                    }
                     if (lane == 0) c = atomicAdd(queue + q_part, 1u);
                     c = __builtin_amdgcn_readfirstlane(c);
                     if (c < p1 - p0) {
