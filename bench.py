@@ -266,6 +266,36 @@ def main():
                     ctx.render_tiles_dev(cam, tiling, rank, local.data_ptr(), args.max_scatters, 0.0)
                     split_mark()
                     comm.gather_tiles(tiling, local.data_ptr(), frame.data_ptr() if rank == 0 else None)
+                # one untimed frame through either exchange: what rt_gather_tiles assembles on rank 0 must be what the
+                # gather through torch.distributed assembles; if not (or if it raises), every rank takes the latter
+                from raytracer_amd import tiles
+                tg = tiles.TileGather(torch, dist, W, H, args.tile, world, rank, "cuda")
+                def step_td():
+                    ctx.render_tiles_dev(cam, tiling, rank, tg.local.data_ptr(), args.max_scatters, 0.0)
+                    split_mark()
+                    gathered = tg.gather()
+                    if rank == 0:
+                        ctx.assemble_tiles_dev(tiling, gathered.data_ptr(), frame.data_ptr())
+                same, why = 1, ""
+                try:
+                    step()
+                    torch.cuda.synchronize()
+                    first = frame.clone() if rank == 0 else None
+                    step_td()
+                    torch.cuda.synchronize()
+                    if rank == 0 and not torch.equal(first, frame):
+                        same, why = 0, "its frame differs from the one gathered through torch.distributed"
+                except Exception as e:
+                    same, why = 0, str(e)
+                agreed = torch.tensor([same], dtype=torch.int32, device="cuda")
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+                del splits[:]
+                if int(agreed.item()) == 0:
+                    gather_path = "torch.distributed.gather (rt_gather_tiles set aside: %s)" % (why or "on another rank")
+                    step = step_td
+                else:
+                    gather_path += ", frame checked against a gather through torch.distributed"
+                    del tg
 
     def fence():
         if dist is not None:
