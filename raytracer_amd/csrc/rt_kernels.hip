@@ -14,10 +14,13 @@
 // ([entry][lane], conflict-free), with a private overflow for pathological depth.  The walk is
 // "while-while": lanes step through internal nodes until every lane of the wave holds a leaf (or is done),
 // then all leaf tests run together - FP64 leaf code is 10-40x a box test, so it must not run lane by lane.
-// The frame pipeline for max_scatters = 0 is four launches: k_rays<0> (closest hit: the winning record per pixel),
-// k_surface (dense: the full surface record of each hit), k_rays<1> (shadow rays, one wave per (tile, light): all
-// lanes aim at the same light; a verdict per ray), k_resolve (dense: the terms of the lights that reach each point in
-// light order, ambient, albedo, gamma).  The ray kernels only walk: what can run densely does.
+// The frame pipeline for max_scatters = 0: k_entry (per 8x8 tile of camera rays: the subtrees its beam can touch, as the
+// wide node its walks start from), k_rays<0> (closest hit: the winning record per pixel), k_surface (dense: the full
+// surface record of each hit), k_entry again (per tile and light, for the shadow beams), k_rays<1> (shadow rays, the 64
+// rays of a (tile, light) group side by side: all aim at the same light; a verdict per ray), then the resolve (dense:
+// the terms of the lights that reach each point in light order, ambient, albedo, gamma) - k_resolve_decided and
+// k_resolve_listed when the lights fit one batch, k_resolve per batch otherwise.  The ray kernels only walk: what can
+// run densely does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
