@@ -357,15 +357,23 @@ DEV float f32_above(double x) {                    // a float >= x (x finite)
     return f;
 }
 
+// QUICK: the reciprocals as len * rcp(d) (v_rcp_f32, one unit in the last place) instead of a division.  That moves a
+// crossing by up to (|plane| + |o|) 2^-23 along the path, a sixteenth of the padding - with the three roundings of a
+// sixty-fourth each still under an eighth of it - and takes twenty-odd instructions out of a set-up that walks through
+// instances repeat at every instance they enter and leave
+// (the 100 M-triangle frame 19.9 -> 19.6 ms).  One-level scenes keep the division: their counting kernels are compared
+// box for box with a CPU walk that divides.
+template <bool QUICK = false>
 DEV void box_ray_init(BoxRay& b, const RayD& r, float radius) {
     const float ox = static_cast<float>(r.ox), oy = static_cast<float>(r.oy), oz = static_cast<float>(r.oz);
     const float m = fmaxf(fmaxf(radius, fabsf(ox)), fmaxf(fabsf(oy), fabsf(oz)));
     const float pad = ldexpf(m, -RT_PAD_SHIFT);
     const float big = 1.2676506e30f;                                  // 2^100
     const float len = static_cast<float>(r.dlen);                     // 1 / (d / |d|) in one FP32 division per axis
-    b.ix = fminf(fmaxf(len / static_cast<float>(r.dx), -big), big);
-    b.iy = fminf(fmaxf(len / static_cast<float>(r.dy), -big), big);
-    b.iz = fminf(fmaxf(len / static_cast<float>(r.dz), -big), big);
+    const float fdx = static_cast<float>(r.dx), fdy = static_cast<float>(r.dy), fdz = static_cast<float>(r.dz);
+    b.ix = fminf(fmaxf(QUICK ? len * __builtin_amdgcn_rcpf(fdx) : len / fdx, -big), big);
+    b.iy = fminf(fmaxf(QUICK ? len * __builtin_amdgcn_rcpf(fdy) : len / fdy, -big), big);
+    b.iz = fminf(fmaxf(QUICK ? len * __builtin_amdgcn_rcpf(fdz) : len / fdz, -big), big);
     const float npx = -(ox + pad) * b.ix, npy = -(oy + pad) * b.iy, npz = -(oz + pad) * b.iz;     // goes with a lower plane
     const float nmx = -(ox - pad) * b.ix, nmy = -(oy - pad) * b.iy, nmz = -(oz - pad) * b.iz;     // goes with an upper plane
     const bool fx = b.ix > 0.0f, fy = b.iy > 0.0f, fz = b.iz > 0.0f;                              // lower plane first
@@ -530,7 +538,7 @@ struct Walker {
     DEV void start(const DevScene& sc, const RayD& ray, uint2* deep_stack, double ldist, const char* entry_base = nullptr, uint32_t entry_off = 0) {
         r = ray;
         if (INST) { world_ray_park(ray); inst = REF_NONE; id_off = 0; }
-        box_ray_init(br, r, sc.radius);
+        box_ray_init<INST>(br, r, sc.radius);
         st.deep = deep_stack; st.reset(threadIdx.x & 63u);
         best.dist = __builtin_inf(); best.slot = 0xFFFFFFFFu; best.id = -1; best.inst = REF_NONE;
         light_dist = ldist; found_mid = false; closed = false;
@@ -618,7 +626,7 @@ struct Walker {
         if (INST) {
             if (cur == REF_LEAVE) {                 // the instance is exhausted: back to the world
                 world_ray_fetch(r); inst = REF_NONE; id_off = 0;
-                box_ray_init(br, r, sc.radius);
+                box_ray_init<INST>(br, r, sc.radius);
                 cur = st.pop(limit_f);
                 return;
             }
@@ -628,7 +636,7 @@ struct Walker {
                 const uint4 tail = *reinterpret_cast<const uint4*>(&in->root_ref);
                 st.push(REF_LEAVE, 0.0f);
                 { const RayD world = r; ray_into_instance(in, world, r); }      // in the top-level tree r is the world ray
-                box_ray_init(br, r, __uint_as_float(tail.z));
+                box_ray_init<INST>(br, r, __uint_as_float(tail.z));
                 inst = slot; id_off = static_cast<int32_t>(tail.y);
                 cur = tail.x;
                 if (COUNT) ++vn;
